@@ -1,0 +1,36 @@
+"""MI355X-native paged-attention backend for baby-sglang's attention hot path.
+
+Host-side mirror of the reference interface (``SimpleAttentionBackend``,
+``SimplifiedForwardBatch``, ``ReqToTokenPool``, ``MHATokenToKVPool``, the
+``tp_runtime`` collectives) over hand-written gfx950 HIP kernels reached
+through the C ABI of ``libbsgl_attn.so`` (include/bsgl_attn.h).  Importing the
+package loads that library and raises if it has not been built.
+"""
+
+from . import _hip
+from .attn_backend import SimpleAttentionBackend
+from .forward_batch import SimplifiedForwardBatch
+from .memory_pool import BaseTokenToKVPool, MHATokenToKVPool, ReqToTokenPool
+from .tp_runtime import (
+    TPLayout,
+    init_tp,
+    tp_all_gather,
+    tp_all_reduce_sum,
+    tp_attention_exchange,
+    tp_broadcast,
+)
+
+__all__ = [
+    "_hip",
+    "SimpleAttentionBackend",
+    "SimplifiedForwardBatch",
+    "BaseTokenToKVPool",
+    "MHATokenToKVPool",
+    "ReqToTokenPool",
+    "TPLayout",
+    "init_tp",
+    "tp_all_gather",
+    "tp_all_reduce_sum",
+    "tp_attention_exchange",
+    "tp_broadcast",
+]

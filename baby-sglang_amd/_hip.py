@@ -1,0 +1,312 @@
+"""ctypes binding of libbsgl_attn.so (C ABI declared in include/bsgl_attn.h).
+
+The library is the only compute path of this package: importing this module
+raises if the shared object has not been built, and every wrapper raises on a
+non-zero return code.  PyTorch is used for device memory and streams only;
+the wrappers pass raw device pointers, element strides and the caller's
+current HIP stream, so calls are safe from any thread and on any stream
+(the reference calls its backend from a side thread on a side stream,
+overlap_worker.py:104-127).
+"""
+
+from __future__ import annotations
+
+import ctypes
+import math
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbsgl_attn.so")
+
+ABI_VERSION = 1
+
+BSGL_OK = 0
+BSGL_ERR_BAD_ARG = -1
+BSGL_ERR_UNSUPPORTED = -2
+BSGL_ERR_HIP = -3
+BSGL_ERR_WORKSPACE = -4
+
+DECODE_AUTO, DECODE_VALU, DECODE_MFMA = 0, 1, 2
+
+_DTYPE_CODE = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
+
+# every symbol include/bsgl_attn.h declares, with its ctypes signature
+_vp, _i64, _i32, _f32, _sz = (
+    ctypes.c_void_p,
+    ctypes.c_int64,
+    ctypes.c_int32,
+    ctypes.c_float,
+    ctypes.c_size_t,
+)
+SIGNATURES = {
+    "bsgl_abi_version": (ctypes.c_int, []),
+    "bsgl_last_error": (ctypes.c_char_p, []),
+    "bsgl_kv_scatter": (
+        ctypes.c_int,
+        [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp],
+    ),
+    "bsgl_decode_num_splits": (_i32, [_i32, _i32, _i32]),
+    "bsgl_decode_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
+    "bsgl_paged_decode": (
+        ctypes.c_int,
+        [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp]
+        + [_i32, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _i32, _vp, _sz, _vp],
+    ),
+    "bsgl_prefill_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "bsgl_paged_prefill": (
+        ctypes.c_int,
+        [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]
+        + [_i32, _i32, _i32, _i32, _i32, _f32, _i32, _i32, _vp, _sz, _vp],
+    ),
+    "bsgl_merge_attn_states": (
+        ctypes.c_int,
+        [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    ),
+}
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+            "(or __graft_entry__.build()); this package has no non-HIP attention path"
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    got = lib.bsgl_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI version {got}, expected {ABI_VERSION}")
+    return lib
+
+
+lib = _load()
+
+
+def _check(rc: int, what: str) -> None:
+    if rc == BSGL_OK:
+        return
+    msg = lib.bsgl_last_error().decode("utf-8", "replace")
+    if rc == BSGL_ERR_UNSUPPORTED:
+        raise NotImplementedError(f"{what}: {msg}")
+    if rc == BSGL_ERR_BAD_ARG:
+        raise ValueError(f"{what}: {msg}")
+    raise RuntimeError(f"{what} failed ({rc}): {msg}")
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    try:
+        return _DTYPE_CODE[t.dtype]
+    except KeyError:
+        raise NotImplementedError(f"dtype {t.dtype} has no HIP attention kernel") from None
+
+
+def _need_gpu(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError(
+                "baby-sglang_amd runs on MI355X only: got a tensor on "
+                f"{t.device}; there is no CPU attention path in this package"
+            )
+
+
+def _stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _rows(x: torch.Tensor) -> torch.Tensor:
+    """[T, heads, dim] (or [T, heads*dim]) view whose inner dims are dense."""
+    if x.dim() == 3:
+        if x.stride(2) != 1 or x.stride(1) != x.shape[2]:
+            x = x.contiguous()
+    elif x.dim() == 2:
+        if x.stride(1) != 1:
+            x = x.contiguous()
+    else:
+        raise ValueError(f"expected a 2-D or 3-D tensor, got shape {tuple(x.shape)}")
+    return x
+
+
+def kv_scatter(k_slab, v_slab, loc, k_new, v_new) -> None:
+    """k_slab[loc] = k_new; v_slab[loc] = v_new (memory_pool.py:152-171)."""
+    _need_gpu(k_slab, v_slab, loc, k_new, v_new)
+    n_tok = int(loc.shape[0])
+    if n_tok == 0:
+        return
+    if loc.dtype != torch.int32:
+        loc = loc.to(torch.int32)
+    if not loc.is_contiguous():
+        loc = loc.contiguous()
+    heads, dim = k_slab.shape[1], k_slab.shape[2]
+    k_new = _rows(k_new.view(n_tok, heads, dim) if k_new.dim() == 2 else k_new)
+    v_new = _rows(v_new.view(n_tok, heads, dim) if v_new.dim() == 2 else v_new)
+    if k_new.shape != (n_tok, heads, dim) or v_new.shape != (n_tok, heads, dim):
+        raise ValueError(
+            f"new K/V rows {tuple(k_new.shape)}/{tuple(v_new.shape)} do not match "
+            f"loc [{n_tok}] and slab heads {heads} x dim {dim}"
+        )
+    if k_slab.stride(0) != v_slab.stride(0):
+        raise ValueError("K and V slabs must share a row stride")
+    rc = lib.bsgl_kv_scatter(
+        k_slab.data_ptr(), v_slab.data_ptr(), k_slab.stride(0), k_slab.shape[0],
+        loc.data_ptr(), k_new.data_ptr(), v_new.data_ptr(),
+        k_new.stride(0), v_new.stride(0), n_tok, heads, dim,
+        _dtype_code(k_slab), _stream_ptr(k_slab.device),
+    )  # fmt: skip
+    _check(rc, "bsgl_kv_scatter")
+
+
+def decode_num_splits(batch: int, n_kv_heads: int, max_context_len: int) -> int:
+    return lib.bsgl_decode_num_splits(batch, n_kv_heads, max_context_len)
+
+
+def decode_workspace_bytes(
+    batch: int, n_q_heads: int, head_dim: int, n_splits: int, out_is_f32: bool = False
+) -> int:
+    return lib.bsgl_decode_workspace_bytes(batch, n_q_heads, head_dim, n_splits, int(out_is_f32))
+
+
+def paged_decode(
+    q: torch.Tensor,
+    k_slab: torch.Tensor,
+    v_slab: torch.Tensor,
+    req_to_token: torch.Tensor,
+    req_pool_indices: torch.Tensor,
+    seq_lens: torch.Tensor,
+    scale: Optional[float] = None,
+    n_splits: Optional[int] = None,
+    variant: int = DECODE_AUTO,
+    out: Optional[torch.Tensor] = None,
+    lse: Optional[torch.Tensor] = None,
+    workspace: Optional[torch.Tensor] = None,
+    out_dtype: Optional[torch.dtype] = None,
+) -> torch.Tensor:
+    """softmax(q K^T * scale) V over page-table rows; returns [B, Hq * D].
+
+    ``out_dtype=torch.float32`` returns unrounded results (with ``lse``, the
+    state a cross-rank merge needs); default is q's dtype.
+    """
+    _need_gpu(q, k_slab, v_slab, req_to_token, req_pool_indices, seq_lens)
+    q = _rows(q)
+    batch, hq, dim = q.shape
+    hkv = k_slab.shape[1]
+    if out_dtype is None:
+        out_dtype = out.dtype if out is not None else q.dtype
+    if out is None:
+        out = torch.empty((batch, hq * dim), dtype=out_dtype, device=q.device)
+    if batch == 0:
+        return out
+    if k_slab.dtype != q.dtype or v_slab.dtype != q.dtype:
+        raise ValueError(f"q is {q.dtype} but the KV slabs are {k_slab.dtype}")
+    if k_slab.stride(0) != v_slab.stride(0):
+        raise ValueError("K and V slabs must share a row stride")
+    if req_pool_indices.dtype != torch.int64:
+        req_pool_indices = req_pool_indices.to(torch.int64)
+    if seq_lens.dtype != torch.int64:
+        seq_lens = seq_lens.to(torch.int64)
+    if req_to_token.dtype != torch.int32 or req_to_token.stride(1) != 1:
+        raise ValueError("req_to_token must be int32 with unit column stride")
+    if scale is None:
+        scale = 1.0 / math.sqrt(dim)
+    if n_splits is None:
+        n_splits = decode_num_splits(batch, hkv, req_to_token.shape[1])
+    need = decode_workspace_bytes(batch, hq, dim, n_splits, out_dtype != q.dtype)
+    if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
+        workspace = torch.empty(need, dtype=torch.uint8, device=q.device)
+    rc = lib.bsgl_paged_decode(
+        out.data_ptr(), out.stride(0), lse.data_ptr() if lse is not None else None,
+        q.data_ptr(), q.stride(0),
+        k_slab.data_ptr(), v_slab.data_ptr(), k_slab.stride(0), k_slab.shape[0],
+        req_to_token.data_ptr(), req_to_token.stride(0), req_to_token.shape[0], req_to_token.shape[1],
+        req_pool_indices.data_ptr(), seq_lens.data_ptr(),
+        batch, hq, hkv, dim, scale, _dtype_code(q), _DTYPE_CODE[out_dtype], n_splits, variant,
+        workspace.data_ptr() if need else None,
+        workspace.numel() * workspace.element_size() if need else 0,
+        _stream_ptr(q.device),
+    )  # fmt: skip
+    _check(rc, "bsgl_paged_decode")
+    return out
+
+
+def prefill_workspace_bytes(batch: int, total_q: int, n_q_heads: int, head_dim: int) -> int:
+    return lib.bsgl_prefill_workspace_bytes(batch, total_q, n_q_heads, head_dim)
+
+
+def paged_prefill(
+    q: torch.Tensor,
+    k_slab: torch.Tensor,
+    v_slab: torch.Tensor,
+    req_to_token: torch.Tensor,
+    req_pool_indices: torch.Tensor,
+    seq_lens: torch.Tensor,
+    prefix_lens: torch.Tensor,
+    extended_lens: torch.Tensor,
+    scale: Optional[float] = None,
+    variant: int = DECODE_AUTO,
+    out: Optional[torch.Tensor] = None,
+    workspace: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    """Extend attention over cached prefixes; returns [T, Hq * D] (T rows of q)."""
+    _need_gpu(q, k_slab, v_slab, req_to_token, req_pool_indices, seq_lens, prefix_lens, extended_lens)
+    q = _rows(q)
+    total_q, hq, dim = q.shape
+    hkv = k_slab.shape[1]
+    batch = int(req_pool_indices.shape[0])
+    if out is None:
+        out = torch.empty((total_q, hq * dim), dtype=q.dtype, device=q.device)
+    if total_q == 0 or batch == 0:
+        return out
+    if k_slab.dtype != q.dtype or v_slab.dtype != q.dtype:
+        raise ValueError(f"q is {q.dtype} but the KV slabs are {k_slab.dtype}")
+    if req_to_token.dtype != torch.int32 or req_to_token.stride(1) != 1:
+        raise ValueError("req_to_token must be int32 with unit column stride")
+    i64 = [
+        t if t.dtype == torch.int64 else t.to(torch.int64)
+        for t in (req_pool_indices, seq_lens, prefix_lens, extended_lens)
+    ]
+    if scale is None:
+        scale = 1.0 / math.sqrt(dim)
+    need = prefill_workspace_bytes(batch, total_q, hq, dim)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=q.device)
+    rc = lib.bsgl_paged_prefill(
+        out.data_ptr(), out.stride(0), q.data_ptr(), q.stride(0),
+        k_slab.data_ptr(), v_slab.data_ptr(), k_slab.stride(0), k_slab.shape[0],
+        req_to_token.data_ptr(), req_to_token.stride(0), req_to_token.shape[0], req_to_token.shape[1],
+        i64[0].data_ptr(), i64[1].data_ptr(), i64[2].data_ptr(), i64[3].data_ptr(),
+        batch, total_q, hq, hkv, dim, scale, _dtype_code(q), variant,
+        workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+        _stream_ptr(q.device),
+    )  # fmt: skip
+    _check(rc, "bsgl_paged_prefill")
+    return out
+
+
+def merge_attn_states(
+    parts_o: torch.Tensor,
+    parts_lse: torch.Tensor,
+    out_dtype: torch.dtype,
+    out: Optional[torch.Tensor] = None,
+    lse_out: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    """Merge [P, rows, H, D] fp32 partial outputs with their [P, rows, H] lse."""
+    _need_gpu(parts_o, parts_lse)
+    n_parts, rows, heads, dim = parts_o.shape
+    parts_o = parts_o.contiguous()
+    parts_lse = parts_lse.contiguous()
+    if parts_o.dtype != torch.float32 or parts_lse.dtype != torch.float32:
+        raise ValueError("partial states must be float32")
+    if out is None:
+        out = torch.empty((rows, heads * dim), dtype=out_dtype, device=parts_o.device)
+    rc = lib.bsgl_merge_attn_states(
+        out.data_ptr(), out.stride(0), lse_out.data_ptr() if lse_out is not None else None,
+        parts_o.data_ptr(), parts_lse.data_ptr(), n_parts, rows, heads, dim,
+        _DTYPE_CODE[out.dtype], _stream_ptr(parts_o.device),
+    )  # fmt: skip
+    _check(rc, "bsgl_merge_attn_states")
+    return out

@@ -1,0 +1,103 @@
+// Host-side launch interface between the C-ABI layer (capi.hip) and the kernel
+// translation units.  Plain structs of device pointers and sizes; every
+// launcher returns hipSuccess or the failing HIP error and never synchronises.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace bsgl {
+
+enum DType : int32_t { kBF16 = 0, kF16 = 1, kF32 = 2 };
+
+inline int dtype_bytes(int32_t dt) { return dt == kF32 ? 4 : 2; }
+
+struct PagedKV {
+  const void* k_slab;
+  const void* v_slab;
+  int64_t slab_row_stride;  // elements between consecutive slots
+  int64_t n_slots;          // rows in a slab (slot ids are clamped to n_slots-1)
+  const int32_t* table;     // req_to_token
+  int64_t table_row_stride;
+  int64_t table_rows;
+  int64_t table_cols;
+};
+
+// One attention "query row": decode has one per request, prefill one per
+// extend token (req / len arrays are then the expanded per-token ones).
+struct DecodeArgs {
+  void* out;
+  int64_t out_row_stride;
+  float* lse;  // optional [rows, n_q_heads], natural log
+  const void* q;
+  int64_t q_row_stride;
+  PagedKV kv;
+  const int64_t* req_idx;   // [rows]
+  const int64_t* seq_lens;  // [rows]
+  int32_t rows;
+  int32_t n_q_heads;
+  int32_t n_kv_heads;
+  int32_t head_dim;
+  float scale;
+  int32_t dtype;
+  int32_t out_dtype;  // dtype, or kF32 (then results always pass through the merge kernel)
+  int32_t n_splits;
+  float* ws_o;    // [n_splits, rows * n_q_heads, head_dim]   (unless direct)
+  float* ws_lse;  // [n_splits, rows * n_q_heads]
+};
+
+struct MergeArgs {
+  void* out;
+  int64_t out_row_stride;
+  float* lse_out;  // optional
+  const float* parts_o;
+  const float* parts_lse;
+  int32_t n_parts;
+  int32_t rows;
+  int32_t n_heads;
+  int32_t head_dim;
+  int32_t dtype;
+};
+
+struct ScatterArgs {
+  void* k_slab;
+  void* v_slab;
+  int64_t slab_row_stride;
+  int64_t n_slots;
+  const int32_t* loc;
+  const void* k_new;
+  const void* v_new;
+  int64_t k_row_stride;
+  int64_t v_row_stride;
+  int32_t n_tok;
+  int32_t row_bytes;  // n_kv_heads * head_dim * sizeof(elem)
+  int32_t elem_bytes;
+};
+
+struct ExpandArgs {
+  const int64_t* req_pool_indices;
+  const int64_t* seq_lens;
+  const int64_t* prefix_lens;
+  const int64_t* extended_lens;
+  int32_t batch;
+  int32_t total_q_tokens;
+  int64_t* cu_ext;   // [batch + 1]
+  int64_t* row_req;  // [total_q_tokens]
+  int64_t* row_len;  // [total_q_tokens]
+};
+
+inline bool decode_direct_out(const DecodeArgs& a) { return a.n_splits == 1 && a.out_dtype == a.dtype; }
+
+// returns false (and leaves *why) when no VALU kernel instance covers the shape
+bool decode_valu_supported(const DecodeArgs& a, const char** why);
+hipError_t launch_decode_valu(const DecodeArgs& a, hipStream_t stream);
+
+bool decode_mfma_supported(const DecodeArgs& a, const char** why);
+hipError_t launch_decode_mfma(const DecodeArgs& a, hipStream_t stream);
+
+hipError_t launch_merge(const MergeArgs& a, hipStream_t stream);
+hipError_t launch_kv_scatter(const ScatterArgs& a, hipStream_t stream);
+hipError_t launch_prefill_expand(const ExpandArgs& a, hipStream_t stream);
+
+}  // namespace bsgl

@@ -1,0 +1,302 @@
+// extern "C" surface of libbsgl_attn.so (declared in include/bsgl_attn.h):
+// argument validation, kernel selection, workspace carving, error reporting.
+// No entry point allocates, synchronises or reads device memory.
+#include "../../include/bsgl_attn.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "bsgl_launch.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int hip_fail(const char* what, hipError_t e) {
+  return fail(BSGL_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+int check_dtype(int32_t dtype) {
+  if (dtype != BSGL_DTYPE_BF16 && dtype != BSGL_DTYPE_F16 && dtype != BSGL_DTYPE_F32)
+    return fail(BSGL_ERR_UNSUPPORTED, "dtype %d is not bf16/f16/f32 (fp8 KV slabs are not supported)", dtype);
+  return BSGL_OK;
+}
+
+int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  if (s == nullptr || *s == '\0') return dflt;
+  return atoi(s);
+}
+
+// shared validation of the paged-KV description and the q/out rows
+int check_paged(const void* out, int64_t out_row_stride, const void* q, int64_t q_row_stride,
+                const bsgl::PagedKV& kv, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim,
+                int32_t dtype) {
+  if (int rc = check_dtype(dtype)) return rc;
+  if (!out || !q || !kv.k_slab || !kv.v_slab || !kv.table)
+    return fail(BSGL_ERR_BAD_ARG, "null device pointer (out/q/k_slab/v_slab/req_to_token)");
+  if (n_q_heads <= 0 || n_kv_heads <= 0 || head_dim <= 0)
+    return fail(BSGL_ERR_BAD_ARG, "head counts and head_dim must be positive");
+  if (n_q_heads % n_kv_heads != 0)
+    return fail(BSGL_ERR_BAD_ARG, "n_q_heads %d is not a multiple of n_kv_heads %d", n_q_heads, n_kv_heads);
+  if (kv.n_slots <= 0 || kv.table_rows <= 0 || kv.table_cols <= 0)
+    return fail(BSGL_ERR_BAD_ARG, "slab / page-table extents must be positive");
+  const int eb = bsgl::dtype_bytes(dtype);
+  if (!aligned16(out) || !aligned16(q) || !aligned16(kv.k_slab) || !aligned16(kv.v_slab))
+    return fail(BSGL_ERR_BAD_ARG, "out, q and KV slabs must be 16-byte aligned");
+  if ((out_row_stride * eb) % 16 || (q_row_stride * eb) % 16 || (kv.slab_row_stride * eb) % 16)
+    return fail(BSGL_ERR_BAD_ARG, "row strides must be multiples of 16 bytes");
+  if (out_row_stride < (int64_t)n_q_heads * head_dim || q_row_stride < (int64_t)n_q_heads * head_dim)
+    return fail(BSGL_ERR_BAD_ARG, "q/out row stride shorter than n_q_heads * head_dim");
+  if (kv.slab_row_stride < (int64_t)n_kv_heads * head_dim)
+    return fail(BSGL_ERR_BAD_ARG, "slab row stride shorter than n_kv_heads * head_dim");
+  if (kv.table_row_stride < kv.table_cols)
+    return fail(BSGL_ERR_BAD_ARG, "page-table row stride shorter than its column count");
+  return BSGL_OK;
+}
+
+int run_decode(const bsgl::DecodeArgs& a, int32_t variant, hipStream_t stream) {
+  const char* why = "";
+  bool use_mfma = false;
+  if (variant == BSGL_DECODE_MFMA) {
+    if (!bsgl::decode_mfma_supported(a, &why)) return fail(BSGL_ERR_UNSUPPORTED, "MFMA decode: %s", why);
+    use_mfma = true;
+  } else if (variant == BSGL_DECODE_AUTO) {
+    use_mfma = bsgl::decode_mfma_supported(a, &why);
+  } else if (variant != BSGL_DECODE_VALU) {
+    return fail(BSGL_ERR_BAD_ARG, "unknown decode variant %d", variant);
+  }
+  if (!use_mfma && !bsgl::decode_valu_supported(a, &why)) return fail(BSGL_ERR_UNSUPPORTED, "decode: %s", why);
+  const hipError_t e = use_mfma ? bsgl::launch_decode_mfma(a, stream) : bsgl::launch_decode_valu(a, stream);
+  if (e != hipSuccess) return hip_fail("decode launch", e);
+  return BSGL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bsgl_abi_version(void) { return 1; }
+
+const char* bsgl_last_error(void) { return g_err; }
+
+int bsgl_kv_scatter(void* k_slab, void* v_slab, int64_t slab_row_stride, int64_t n_slots,
+                    const int32_t* loc, const void* k_new, const void* v_new,
+                    int64_t k_row_stride, int64_t v_row_stride, int32_t n_tok,
+                    int32_t n_kv_heads, int32_t head_dim, int32_t dtype, void* stream) {
+  if (int rc = check_dtype(dtype)) return rc;
+  if (n_tok < 0) return fail(BSGL_ERR_BAD_ARG, "n_tok < 0");
+  if (n_tok == 0) return BSGL_OK;
+  if (!k_slab || !v_slab || !loc || !k_new || !v_new)
+    return fail(BSGL_ERR_BAD_ARG, "null device pointer (k_slab/v_slab/loc/k_new/v_new)");
+  if (n_kv_heads <= 0 || head_dim <= 0 || n_slots <= 0)
+    return fail(BSGL_ERR_BAD_ARG, "n_kv_heads, head_dim and n_slots must be positive");
+  const int eb = bsgl::dtype_bytes(dtype);
+  const int64_t row_bytes = (int64_t)n_kv_heads * head_dim * eb;
+  if (row_bytes % 16) return fail(BSGL_ERR_UNSUPPORTED, "KV row of %lld bytes is not a multiple of 16", (long long)row_bytes);
+  if (!aligned16(k_slab) || !aligned16(v_slab) || !aligned16(k_new) || !aligned16(v_new))
+    return fail(BSGL_ERR_BAD_ARG, "slabs and new K/V rows must be 16-byte aligned");
+  if ((slab_row_stride * eb) % 16 || (k_row_stride * eb) % 16 || (v_row_stride * eb) % 16)
+    return fail(BSGL_ERR_BAD_ARG, "row strides must be multiples of 16 bytes");
+  if (slab_row_stride * eb < row_bytes || k_row_stride * eb < row_bytes || v_row_stride * eb < row_bytes)
+    return fail(BSGL_ERR_BAD_ARG, "a row stride is shorter than the KV row");
+  bsgl::ScatterArgs a;
+  a.k_slab = k_slab;
+  a.v_slab = v_slab;
+  a.slab_row_stride = slab_row_stride;
+  a.n_slots = n_slots;
+  a.loc = loc;
+  a.k_new = k_new;
+  a.v_new = v_new;
+  a.k_row_stride = k_row_stride;
+  a.v_row_stride = v_row_stride;
+  a.n_tok = n_tok;
+  a.row_bytes = (int32_t)row_bytes;
+  a.elem_bytes = eb;
+  const hipError_t e = bsgl::launch_kv_scatter(a, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail("kv_scatter launch", e);
+  return BSGL_OK;
+}
+
+int32_t bsgl_decode_num_splits(int32_t batch, int32_t n_kv_heads, int32_t max_context_len) {
+  (void)n_kv_heads;
+  if (batch <= 0) return 1;
+  // enough workgroups to put several on each of the 256 CUs, but no split
+  // shorter than min_chunk tokens of the longest possible request
+  const int target_wgs = env_int("BSGL_DECODE_TARGET_WGS", 1024);
+  const int min_chunk = env_int("BSGL_DECODE_MIN_CHUNK", 128);
+  int splits = (target_wgs + batch - 1) / batch;
+  const int by_len = max_context_len > 0 ? (max_context_len + min_chunk - 1) / min_chunk : 1;
+  if (splits > by_len) splits = by_len;
+  if (splits > 64) splits = 64;
+  if (splits < 1) splits = 1;
+  return splits;
+}
+
+size_t bsgl_decode_workspace_bytes(int32_t batch, int32_t n_q_heads, int32_t head_dim, int32_t n_splits,
+                                   int32_t out_is_f32) {
+  if (batch <= 0 || n_splits < 1 || (n_splits == 1 && !out_is_f32)) return 0;
+  const size_t rh = (size_t)batch * (size_t)n_q_heads;
+  return align_up((size_t)n_splits * rh * (size_t)head_dim * 4, 256) + align_up((size_t)n_splits * rh * 4, 256);
+}
+
+int bsgl_paged_decode(void* out, int64_t out_row_stride, float* lse, const void* q, int64_t q_row_stride,
+                      const void* k_slab, const void* v_slab, int64_t slab_row_stride, int64_t n_slots,
+                      const int32_t* req_to_token, int64_t table_row_stride, int64_t table_rows,
+                      int64_t table_cols, const int64_t* req_pool_indices, const int64_t* seq_lens,
+                      int32_t batch, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim, float scale,
+                      int32_t dtype, int32_t out_dtype, int32_t n_splits, int32_t variant,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+  if (batch < 0) return fail(BSGL_ERR_BAD_ARG, "batch < 0");
+  if (out_dtype != dtype && out_dtype != BSGL_DTYPE_F32)
+    return fail(BSGL_ERR_BAD_ARG, "out_dtype must equal dtype or be f32");
+  if (batch == 0) return BSGL_OK;
+  bsgl::DecodeArgs a;
+  a.kv = {k_slab, v_slab, slab_row_stride, n_slots, req_to_token, table_row_stride, table_rows, table_cols};
+  if (int rc = check_paged(out, out_row_stride, q, q_row_stride, a.kv, n_q_heads, n_kv_heads, head_dim, dtype)) return rc;
+  if (!req_pool_indices || !seq_lens) return fail(BSGL_ERR_BAD_ARG, "null req_pool_indices / seq_lens");
+  if (n_splits < 1 || n_splits > 64) return fail(BSGL_ERR_BAD_ARG, "n_splits %d outside [1, 64]", n_splits);
+  const int f32_out = out_dtype != dtype;
+  if (f32_out && (((uintptr_t)out & 15u) || (out_row_stride * 4) % 16))
+    return fail(BSGL_ERR_BAD_ARG, "f32 out must be 16-byte aligned with a 16-byte-multiple row stride");
+  const size_t need = bsgl_decode_workspace_bytes(batch, n_q_heads, head_dim, n_splits, f32_out);
+  if (need > 0 && (workspace == nullptr || workspace_bytes < need || !aligned16(workspace)))
+    return fail(BSGL_ERR_WORKSPACE, "decode with %d splits needs a 16-byte aligned workspace of %zu bytes (got %zu)", n_splits, need, workspace ? workspace_bytes : (size_t)0);
+  a.out = out;
+  a.out_row_stride = out_row_stride;
+  a.lse = lse;
+  a.q = q;
+  a.q_row_stride = q_row_stride;
+  a.req_idx = req_pool_indices;
+  a.seq_lens = seq_lens;
+  a.rows = batch;
+  a.n_q_heads = n_q_heads;
+  a.n_kv_heads = n_kv_heads;
+  a.head_dim = head_dim;
+  a.scale = scale;
+  a.dtype = dtype;
+  a.out_dtype = out_dtype;
+  a.n_splits = n_splits;
+  const size_t rh = (size_t)batch * (size_t)n_q_heads;
+  a.ws_o = (float*)workspace;
+  a.ws_lse = need ? (float*)((char*)workspace + align_up((size_t)n_splits * rh * (size_t)head_dim * 4, 256)) : nullptr;
+  return run_decode(a, variant, (hipStream_t)stream);
+}
+
+static int32_t prefill_row_splits(int32_t total_q_tokens, int32_t max_context_len) {
+  return bsgl_decode_num_splits(total_q_tokens, 1, max_context_len);
+}
+
+size_t bsgl_prefill_workspace_bytes(int32_t batch, int32_t total_q_tokens, int32_t n_q_heads, int32_t head_dim) {
+  if (batch <= 0 || total_q_tokens <= 0) return 0;
+  // cu_ext[batch + 1], row_req[T], row_len[T], then split partials sized for the
+  // worst case over context lengths (64 splits only when T is tiny)
+  size_t bytes = align_up((size_t)(batch + 1) * 8, 256) + 2 * align_up((size_t)total_q_tokens * 8, 256);
+  const int32_t splits = prefill_row_splits(total_q_tokens, 1 << 30);
+  bytes += bsgl_decode_workspace_bytes(total_q_tokens, n_q_heads, head_dim, splits, 0);
+  return bytes;
+}
+
+int bsgl_paged_prefill(void* out, int64_t out_row_stride, const void* q, int64_t q_row_stride,
+                       const void* k_slab, const void* v_slab, int64_t slab_row_stride, int64_t n_slots,
+                       const int32_t* req_to_token, int64_t table_row_stride, int64_t table_rows,
+                       int64_t table_cols, const int64_t* req_pool_indices, const int64_t* seq_lens,
+                       const int64_t* prefix_lens, const int64_t* extended_lens, int32_t batch,
+                       int32_t total_q_tokens, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim,
+                       float scale, int32_t dtype, int32_t variant, void* workspace,
+                       size_t workspace_bytes, void* stream) {
+  if (batch < 0 || total_q_tokens < 0) return fail(BSGL_ERR_BAD_ARG, "batch / total_q_tokens < 0");
+  if (batch == 0 || total_q_tokens == 0) return BSGL_OK;
+  bsgl::DecodeArgs a;
+  a.kv = {k_slab, v_slab, slab_row_stride, n_slots, req_to_token, table_row_stride, table_rows, table_cols};
+  if (int rc = check_paged(out, out_row_stride, q, q_row_stride, a.kv, n_q_heads, n_kv_heads, head_dim, dtype)) return rc;
+  if (!req_pool_indices || !seq_lens || !prefix_lens || !extended_lens)
+    return fail(BSGL_ERR_BAD_ARG, "null req_pool_indices / seq_lens / prefix_lens / extended_lens");
+  const size_t need = bsgl_prefill_workspace_bytes(batch, total_q_tokens, n_q_heads, head_dim);
+  if (workspace == nullptr || workspace_bytes < need || !aligned16(workspace))
+    return fail(BSGL_ERR_WORKSPACE, "prefill needs a 16-byte aligned workspace of %zu bytes (got %zu)", need, workspace ? workspace_bytes : (size_t)0);
+
+  char* ws = (char*)workspace;
+  bsgl::ExpandArgs ex;
+  ex.req_pool_indices = req_pool_indices;
+  ex.seq_lens = seq_lens;
+  ex.prefix_lens = prefix_lens;
+  ex.extended_lens = extended_lens;
+  ex.batch = batch;
+  ex.total_q_tokens = total_q_tokens;
+  ex.cu_ext = (int64_t*)ws;
+  ws += align_up((size_t)(batch + 1) * 8, 256);
+  ex.row_req = (int64_t*)ws;
+  ws += align_up((size_t)total_q_tokens * 8, 256);
+  ex.row_len = (int64_t*)ws;
+  ws += align_up((size_t)total_q_tokens * 8, 256);
+  hipError_t e = bsgl::launch_prefill_expand(ex, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail("prefill expand launch", e);
+
+  // every q row is an independent attention row over a length-limited page-table row
+  const int32_t splits = prefill_row_splits(total_q_tokens, (int32_t)(table_cols > (1 << 30) ? (1 << 30) : table_cols));
+  a.out = out;
+  a.out_row_stride = out_row_stride;
+  a.lse = nullptr;
+  a.q = q;
+  a.q_row_stride = q_row_stride;
+  a.req_idx = ex.row_req;
+  a.seq_lens = ex.row_len;
+  a.rows = total_q_tokens;
+  a.n_q_heads = n_q_heads;
+  a.n_kv_heads = n_kv_heads;
+  a.head_dim = head_dim;
+  a.scale = scale;
+  a.dtype = dtype;
+  a.out_dtype = dtype;
+  a.n_splits = splits;
+  const size_t rh = (size_t)total_q_tokens * (size_t)n_q_heads;
+  a.ws_o = (float*)ws;
+  a.ws_lse = splits > 1 ? (float*)(ws + align_up((size_t)splits * rh * (size_t)head_dim * 4, 256)) : nullptr;
+  (void)variant;
+  return run_decode(a, BSGL_DECODE_VALU, (hipStream_t)stream);
+}
+
+int bsgl_merge_attn_states(void* out, int64_t out_row_stride, float* lse_out, const float* parts_o,
+                           const float* parts_lse, int32_t n_parts, int32_t rows, int32_t n_heads,
+                           int32_t head_dim, int32_t dtype, void* stream) {
+  if (int rc = check_dtype(dtype)) return rc;
+  if (rows < 0 || n_parts < 1 || n_heads <= 0) return fail(BSGL_ERR_BAD_ARG, "rows < 0, n_parts < 1 or n_heads <= 0");
+  if (rows == 0) return BSGL_OK;
+  if (head_dim != 64 && head_dim != 128) return fail(BSGL_ERR_UNSUPPORTED, "head_dim must be 64 or 128");
+  if (!out || !parts_o || !parts_lse) return fail(BSGL_ERR_BAD_ARG, "null device pointer (out/parts_o/parts_lse)");
+  const int eb = bsgl::dtype_bytes(dtype);
+  if (!aligned16(out) || !aligned16(parts_o) || (out_row_stride * eb) % 16)
+    return fail(BSGL_ERR_BAD_ARG, "out / parts_o must be 16-byte aligned with 16-byte-multiple row stride");
+  if (out_row_stride < (int64_t)n_heads * head_dim) return fail(BSGL_ERR_BAD_ARG, "out row stride shorter than n_heads * head_dim");
+  bsgl::MergeArgs m;
+  m.out = out;
+  m.out_row_stride = out_row_stride;
+  m.lse_out = lse_out;
+  m.parts_o = parts_o;
+  m.parts_lse = parts_lse;
+  m.n_parts = n_parts;
+  m.rows = rows;
+  m.n_heads = n_heads;
+  m.head_dim = head_dim;
+  m.dtype = dtype;
+  const hipError_t e = bsgl::launch_merge(m, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail("merge launch", e);
+  return BSGL_OK;
+}
+
+}  // extern "C"

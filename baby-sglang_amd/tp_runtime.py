@@ -1,0 +1,199 @@
+"""Tensor-parallel runtime for the attention path: one process per GPU,
+``torch.distributed`` over RCCL (backend ``"nccl"`` on ROCm) across xGMI.
+
+The four wrappers keep the reference's names and semantics (reference:
+tp_runtime.py:10-51): ``init_tp`` reads ``RANK`` / ``WORLD_SIZE`` /
+``LOCAL_RANK`` (torchrun), ``tp_all_reduce_sum`` and ``tp_broadcast`` work in
+place, ``tp_all_gather`` concatenates along dim 0.  One deliberate difference:
+with a world of one they are true no-ops and need no process group (the
+reference asks ``dist.get_world_size`` even then, tp_runtime.py:29, which
+raises when no group was initialised).
+
+The reference stops at the collectives; how attention is sharded is this
+module's ``TPLayout``.  kv heads are split first (rank owns whole kv heads and
+their q-head groups, its own KV slabs and nothing to merge).  When the world is
+larger than the number of kv heads (Qwen2.5-1.5B has 2), the ranks of a kv head
+additionally split every request's tokens round-robin by position, each rank
+holding its tokens in its own pool under a local page table; partial results
+``(o, lse)`` are exchanged with ONE all-gather per layer and merged by
+``bsgl_merge_attn_states``.  Messages are ~100-200 KiB, i.e. latency-bound on
+xGMI, so there is exactly one collective per layer and no ring of small steps.
+"""
+
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_tp(backend: Optional[str] = None) -> Tuple[int, int, object]:
+    rank = int(os.getenv("RANK", "0"))
+    world_size = int(os.getenv("WORLD_SIZE", "1"))
+    local_rank = int(os.getenv("LOCAL_RANK", "0"))
+
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+
+    if world_size > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kwargs = {}
+        if backend == "nccl":
+            kwargs["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, **kwargs)
+
+    tp_group = dist.group.WORLD if dist.is_initialized() else None
+    if dist.is_initialized():
+        rank = dist.get_rank(group=tp_group)
+        world_size = dist.get_world_size(group=tp_group)
+    return rank, world_size, tp_group
+
+
+def _world(tp_group) -> int:
+    if not dist.is_initialized():
+        return 1
+    return dist.get_world_size(group=tp_group)
+
+
+def tp_all_reduce_sum(x: torch.Tensor, tp_group) -> torch.Tensor:
+    if _world(tp_group) == 1:
+        return x
+    dist.all_reduce(x, op=dist.ReduceOp.SUM, group=tp_group)
+    return x
+
+
+def tp_all_gather(x: torch.Tensor, tp_group) -> torch.Tensor:
+    world = _world(tp_group)
+    if world == 1:
+        return x
+    out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x.contiguous(), group=tp_group)
+    return out
+
+
+def tp_broadcast(x: torch.Tensor, src: int, tp_group) -> torch.Tensor:
+    if _world(tp_group) == 1:
+        return x
+    dist.broadcast(x, src=src, group=tp_group)
+    return x
+
+
+@dataclass(frozen=True)
+class TPLayout:
+    """Which kv heads and which token positions a rank owns.
+
+    world = tp_kv * tp_seq; ranks of one kv-head shard are consecutive:
+    ``rank = kv_rank * tp_seq + seq_rank``.
+    """
+
+    rank: int
+    world: int
+    n_q_heads: int
+    n_kv_heads: int
+
+    def __post_init__(self):
+        if self.world < 1 or not (0 <= self.rank < self.world):
+            raise ValueError(f"rank {self.rank} outside world {self.world}")
+        if self.n_q_heads % self.n_kv_heads:
+            raise ValueError("n_q_heads must be a multiple of n_kv_heads")
+        kv = min(self.world, self.n_kv_heads)
+        if self.n_kv_heads % kv or self.world % kv:
+            raise ValueError(
+                f"world {self.world} cannot shard {self.n_kv_heads} kv heads: it must divide "
+                "the kv-head count or be a multiple of it"
+            )
+
+    @property
+    def tp_kv(self) -> int:
+        return min(self.world, self.n_kv_heads)
+
+    @property
+    def tp_seq(self) -> int:
+        return self.world // self.tp_kv
+
+    @property
+    def kv_rank(self) -> int:
+        return self.rank // self.tp_seq
+
+    @property
+    def seq_rank(self) -> int:
+        return self.rank % self.tp_seq
+
+    @property
+    def group(self) -> int:
+        return self.n_q_heads // self.n_kv_heads
+
+    @property
+    def local_kv_heads(self) -> int:
+        return self.n_kv_heads // self.tp_kv
+
+    @property
+    def local_q_heads(self) -> int:
+        return self.local_kv_heads * self.group
+
+    @property
+    def kv_head_range(self) -> Tuple[int, int]:
+        lo = self.kv_rank * self.local_kv_heads
+        return lo, lo + self.local_kv_heads
+
+    @property
+    def q_head_range(self) -> Tuple[int, int]:
+        lo, hi = self.kv_head_range
+        return lo * self.group, hi * self.group
+
+    def owns_position(self, pos: int) -> bool:
+        return pos % self.tp_seq == self.seq_rank
+
+    def local_len(self, seq_lens: torch.Tensor) -> torch.Tensor:
+        """Number of positions p < seq_len with p % tp_seq == seq_rank."""
+        return (seq_lens - self.seq_rank + self.tp_seq - 1).clamp_min(0) // self.tp_seq
+
+    def shard_q(self, q: torch.Tensor) -> torch.Tensor:
+        lo, hi = self.q_head_range
+        return q[:, lo:hi]
+
+    def shard_kv(self, kv: torch.Tensor) -> torch.Tensor:
+        lo, hi = self.kv_head_range
+        return kv[:, lo:hi]
+
+
+def tp_attention_exchange(
+    layout: TPLayout,
+    local_out: torch.Tensor,
+    local_lse: Optional[torch.Tensor],
+    tp_group,
+    out_dtype: torch.dtype,
+    merge_fn: Optional[Callable] = None,
+) -> torch.Tensor:
+    """Full ``[rows, n_q_heads * head_dim]`` attention output on every rank.
+
+    ``local_out`` is this rank's ``[rows, local_q_heads * head_dim]`` result: in
+    ``out_dtype`` when tokens are not split (tp_seq == 1), fp32 with
+    ``local_lse`` ``[rows, local_q_heads]`` otherwise.  One all-gather either way.
+    ``merge_fn(parts_o [P,R,H,D], parts_lse [P,R,H], dtype) -> [R, H*D]``
+    defaults to the HIP merge kernel.
+    """
+    rows = local_out.shape[0]
+    hq_l = layout.local_q_heads
+    dim = local_out.shape[1] // hq_l
+    if layout.world == 1:
+        return local_out if local_out.dtype == out_dtype else local_out.to(out_dtype)
+    if layout.tp_seq == 1:
+        gathered = tp_all_gather(local_out.unsqueeze(0), tp_group)  # [world, rows, hq_l*D]
+        return gathered.permute(1, 0, 2).reshape(rows, layout.n_q_heads * dim)
+    if merge_fn is None:
+        from . import _hip
+
+        merge_fn = _hip.merge_attn_states
+    state = torch.cat(
+        (local_out.view(rows, hq_l, dim).float(), local_lse.view(rows, hq_l, 1).float()), dim=-1
+    )
+    gathered = tp_all_gather(state.unsqueeze(0), tp_group)  # [world, rows, hq_l, D+1]
+    gathered = gathered.view(layout.tp_kv, layout.tp_seq, rows, hq_l, dim + 1)
+    parts = gathered.permute(1, 0, 2, 3, 4).reshape(layout.tp_seq, layout.tp_kv * rows, hq_l, dim + 1)
+    merged = merge_fn(parts[..., :dim].contiguous(), parts[..., dim].contiguous(), out_dtype)
+    return merged.view(layout.tp_kv, rows, hq_l * dim).permute(1, 0, 2).reshape(rows, layout.n_q_heads * dim)

@@ -1,0 +1,370 @@
+#!/usr/bin/env python3
+"""Decode-step benchmark of the paged-attention path on MI355X.
+
+A step = one pass of the attention hot path over one synthetic decode batch:
+for each of the 28 layers, ``SimpleAttentionBackend.forward(q, k, v, layer, fb)``
+(KV write of the new token + paged decode attention over the whole context).
+Workload (BASELINE.json configs[2], Qwen2.5-1.5B shapes): batch 64, every
+request at sequence length 2048, 12 q heads / 2 kv heads / head_dim 128, bf16,
+one KV slab pair per layer, random-permutation page table (worst-case scatter).
+
+  python bench.py [--gpus N --steps K --warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  ``value`` is decode tokens/s of the whole job
+with every input resident in HBM.  ``roofline`` prices the dominant kernel (the
+split-KV decode kernel) against HBM bandwidth with algorithmic bytes;
+``cpu_baseline`` times the oracle's reference-style torch-CPU backend on a
+bounded sample of the same workload on this box's host cores.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--seq", type=int, default=2048)
+    ap.add_argument("--layers", type=int, default=28)
+    ap.add_argument("--max-context", type=int, default=4096)
+    ap.add_argument("--table", choices=["perm", "contig"], default="perm")
+    ap.add_argument("--kv-layout", choices=["interleaved", "split"], default="interleaved")
+    ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 generic, 2 matrix-core decode kernel")
+    ap.add_argument("--splits", type=int, default=0, help="sequence splits (0 = library heuristic)")
+    ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
+                    help="replay the 28-layer step from a HIP graph, or launch it from Python each step")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the contiguous-table and eager/graph side measurements")
+    return ap.parse_args()
+
+
+class Workload:
+    """Per-rank synthetic decode state in HBM."""
+
+    def __init__(self, args, dev, layout):
+        import baby_sglang_amd as pkg
+
+        self.pkg = pkg
+        self.args = args
+        self.dev = dev
+        self.layout = layout
+        B, S, L = args.batch, args.seq, args.layers
+        self.hq, self.hkv, self.dim = 12, 2, 128
+        self.hq_l, self.hkv_l = layout.local_q_heads, layout.local_kv_heads
+        self.dtype = torch.bfloat16
+        gen = torch.Generator(device=dev).manual_seed(1234 + layout.rank)
+        # this rank's share of every request's tokens (round-robin by position when tp_seq > 1)
+        seq = torch.full((B,), S, dtype=torch.int64, device=dev)
+        self.local_seq = layout.local_len(seq)
+        s_loc = int(self.local_seq.max().item())
+        self.s_loc = s_loc
+        size = B * args.max_context // layout.tp_seq
+        self.r2t = pkg.ReqToTokenPool(B, args.max_context, str(dev))
+        self.kv = pkg.MHATokenToKVPool(size, self.dtype, self.hkv_l, self.dim, L, str(dev), kv_layout=args.kv_layout)
+        self.kv.arena.normal_(generator=gen)
+        self.tables = {}
+        perm = torch.randperm(B * s_loc, generator=gen, device=dev).to(torch.int32) + 1
+        t = torch.zeros((B, args.max_context), dtype=torch.int32, device=dev)
+        t[:, :s_loc] = perm.view(B, s_loc)
+        self.tables["perm"] = t
+        t = torch.zeros((B, args.max_context), dtype=torch.int32, device=dev)
+        t[:, :s_loc] = (torch.arange(B * s_loc, device=dev, dtype=torch.int32) + 1).view(B, s_loc)
+        self.tables["contig"] = t
+        self.q = torch.randn((L, B, self.hq_l, self.dim), generator=gen, device=dev).to(self.dtype)
+        self.k = torch.randn((L, B, self.hkv_l, self.dim), generator=gen, device=dev).to(self.dtype)
+        # v as the model hands it over: a column slice of a wider projection row
+        self.v_parent = torch.randn((L, B, (self.hq_l + 2 * self.hkv_l) * self.dim), generator=gen, device=dev).to(self.dtype)
+        self.layers = [types.SimpleNamespace(layer_id=i, scaling=self.dim**-0.5) for i in range(L)]
+        self.req = torch.arange(B, dtype=torch.int64, device=dev)
+        self.writes_kv = layout.owns_position(S - 1)
+        self.set_table(args.table)
+        self.n_splits = args.splits or pkg._hip.decode_num_splits(B, self.hkv_l, args.max_context)
+        self.out_f32 = layout.tp_seq > 1
+        ws = pkg._hip.decode_workspace_bytes(B, self.hq_l, self.dim, self.n_splits, self.out_f32)
+        self.workspace = torch.empty(max(ws, 16), dtype=torch.uint8, device=dev)
+        self.lse = torch.empty((B, self.hq_l), dtype=torch.float32, device=dev) if self.out_f32 else None
+        self.out = torch.empty((B, self.hq_l * self.dim), dtype=torch.float32 if self.out_f32 else self.dtype, device=dev)
+        self.full_out = None
+
+    def set_table(self, kind):
+        self.r2t.req_to_token.copy_(self.tables[kind])
+        # slot of the token written this step = last local position of each request
+        self.loc = self.r2t.req_to_token[self.req, (self.local_seq - 1).clamp_min(0)].contiguous()
+        self.fb = self.pkg.SimplifiedForwardBatch.create_decode_batch(
+            torch.zeros(self.args.batch, dtype=torch.int64, device=self.dev), self.req, self.local_seq,
+            self.loc, self.r2t, self.kv,
+        )
+
+    def v_rows(self, layer):
+        c0 = (self.hq_l + self.hkv_l) * self.dim
+        return self.v_parent[layer][:, c0:].view(self.args.batch, self.hkv_l, self.dim)
+
+    def attention_layer(self, layer, tp_group=None):
+        """KV write + paged decode (+ the TP exchange) of one layer."""
+        hip = self.pkg._hip
+        if self.writes_kv:
+            self.kv.set_kv_buffer(layer, self.loc, self.k[layer], self.v_rows(layer))
+        k_slab, v_slab = self.kv.get_kv_buffer(layer)
+        hip.paged_decode(
+            self.q[layer], k_slab, v_slab, self.r2t.req_to_token, self.req, self.local_seq,
+            n_splits=self.n_splits, variant=self.args.variant, out=self.out, lse=self.lse,
+            workspace=self.workspace,
+        )
+        if self.layout.world > 1:
+            self.full_out = self.pkg.tp_attention_exchange(self.layout, self.out, self.lse, tp_group, self.dtype)
+
+    def step(self, tp_group=None):
+        for layer in range(self.args.layers):
+            self.attention_layer(layer, tp_group)
+
+    def backend_step(self):
+        """The same step through the reference-shaped entry point (1 GPU)."""
+        fwd = self.pkg.SimpleAttentionBackend.forward
+        for layer in range(self.args.layers):
+            fwd(self.q[layer], self.k[layer], self.v_rows(layer), self.layers[layer], self.fb)
+
+    def algorithmic_bytes_per_layer(self):
+        B, D, eb = self.args.batch, self.dim, 2
+        tokens = int(self.local_seq.sum().item())
+        kv = 2 * tokens * self.hkv_l * D * eb
+        table = tokens * 4
+        q = B * self.hq_l * D * eb
+        out = B * self.hq_l * D * (4 if self.out_f32 else eb)
+        new_kv = 2 * B * self.hkv_l * D * eb if self.writes_kv else 0
+        return kv + table + q + out + new_kv, kv
+
+
+def barrier(world):
+    if world > 1:
+        torch.distributed.barrier()
+
+
+def timed_steps(fn, steps, warmup, world):
+    """Barrier + device sync on both sides; wall time of exactly `steps` calls; max over ranks."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    barrier(world)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    barrier(world)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def make_runner(wl, mode, tp_group):
+    if mode == "eager":
+        return lambda: wl.step(tp_group)
+    # capture the whole 28-layer step once, replay it per step
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            wl.step(tp_group)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        wl.step(tp_group)
+    return graph.replay
+
+
+def kernel_event_times(wl, steps):
+    """HIP-event time of the decode launches alone (split kernel + merge), one
+    event pair per layer call on the launch stream, averaged over steps * layers."""
+    hip = wl.pkg._hip
+    L = wl.args.layers
+    stream = torch.cuda.current_stream()
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(L)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(L)]
+    total_ms, n = 0.0, 0
+    for it in range(steps + 1):
+        for layer in range(L):
+            k_slab, v_slab = wl.kv.get_kv_buffer(layer)
+            starts[layer].record(stream)
+            hip.paged_decode(wl.q[layer], k_slab, v_slab, wl.r2t.req_to_token, wl.req, wl.local_seq,
+                             n_splits=wl.n_splits, variant=wl.args.variant, out=wl.out, lse=wl.lse,
+                             workspace=wl.workspace)
+            ends[layer].record(stream)
+        torch.cuda.synchronize()
+        if it == 0:
+            continue  # warm-up round
+        total_ms += sum(s.elapsed_time(e) for s, e in zip(starts, ends))
+        n += L
+    return total_ms / n
+
+
+def cpu_baseline(args, budget_s):
+    """Reference-style torch-CPU backend (oracle/attn_oracle.py: per-request
+    gather -> GQA repeat -> SDPA, bf16) on ONE layer of the same workload, repeated
+    for about `budget_s` seconds; tokens/s = batch / (layers * seconds per layer)."""
+    from oracle import attn_oracle as orc
+
+    B, S = args.batch, args.seq
+    hq, hkv, dim, dtype = 12, 2, 128, torch.bfloat16
+    gen = torch.Generator().manual_seed(0)
+    n_slots = B * S + 1
+    k_slab = torch.randn((n_slots, hkv, dim), generator=gen).to(dtype)
+    v_slab = torch.randn((n_slots, hkv, dim), generator=gen).to(dtype)
+    table = torch.zeros((B, args.max_context), dtype=torch.int32)
+    table[:, :S] = (torch.randperm(B * S, generator=gen) + 1).to(torch.int32).view(B, S)
+    req = torch.arange(B)
+    seq = torch.full((B,), S, dtype=torch.int64)
+    q = torch.randn((B, hq, dim), generator=gen).to(dtype)
+    k = torch.randn((B, hkv, dim), generator=gen).to(dtype)
+    v = torch.randn((B, hkv, dim), generator=gen).to(dtype)
+    loc = table[req, seq - 1]
+
+    def one_layer():
+        return orc.forward_ref(q, k, v, k_slab, v_slab, table, req, seq, loc, is_prefill=False)
+
+    one_layer()
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        one_layer()
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or reps >= 2000:
+            break
+    per_layer = dt / reps
+    return {
+        "value": B / (per_layer * args.layers),
+        "unit": "tokens/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"1 of {args.layers} layers of the same batch ({B} x seq {S}, bf16, random-permutation table), "
+                  f"{reps} reps in {dt:.1f} s, scaled x{args.layers}; host has {os.cpu_count()} logical CPUs",
+        "ms_per_layer": per_layer * 1e3,
+    }
+
+
+def read_traffic():
+    """HBM bytes per decode launch from a committed rocprofv3 --pmc summary, if any."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    args = parse_args()
+    world = int(os.getenv("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    import baby_sglang_amd as pkg
+
+    rank, world, tp_group = pkg.init_tp()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    layout = pkg.TPLayout(rank, world, 12, 2)
+    wl = Workload(args, dev, layout)
+
+    if world > 1:
+        args.mode = "eager"  # collectives are issued by torch.distributed from Python each layer
+    runner = make_runner(wl, args.mode, tp_group)
+    dt = timed_steps(runner, args.steps, args.warmup, world)
+    ms_per_step = dt / args.steps * 1e3
+    tokens_per_s = args.batch * args.steps / dt
+
+    result = {
+        "metric": "decode tokens/s, paged-attention path, Qwen2.5-1.5B shapes bs=64 seq=2048",
+        "value": tokens_per_s,
+        "unit": "tokens/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong" if world > 1 else "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic (N(0,1) q/k/v and KV slabs, random-permutation page table, torch.manual_seed)",
+        "config": {
+            "workload": f"BASELINE configs[2]: Qwen2.5-1.5B bf16 decode, batch={args.batch}, seq={args.seq}, "
+                        f"{args.layers} layers x (KV write + paged decode attention), Hq=12 Hkv=2 D=128, "
+                        f"page table={args.table}, kv_layout={args.kv_layout}",
+            "global_batch": args.batch,
+            "seq_len": args.seq,
+            "parallelism": "single GPU" if world == 1 else
+                           f"tp{world} = {layout.tp_kv} kv-head shards x {layout.tp_seq} sequence slices, one all-gather per layer",
+            "launch": args.mode,
+            "n_splits": wl.n_splits,
+            "decode_variant": args.variant,
+        },
+    }
+
+    if rank == 0 or world > 1:
+        # per-launch event timing of the dominant kernel, on every rank (keeps ranks in step), reported by rank 0
+        ev_ms = kernel_event_times(wl, max(2, min(args.steps, 10)))
+        total_b, kv_b = wl.algorithmic_bytes_per_layer()
+        achieved = total_b / (ev_ms * 1e-3) / 1e9
+        result["roofline"] = {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": read_traffic() if world == 1 else None,
+            "kernel": "paged decode (split-KV kernel + merge), one layer, HIP events around each launch",
+            "algorithmic_bytes_per_launch": total_b,
+            "kv_bytes_per_launch": kv_b,
+            "avg_launch_us": ev_ms * 1e3,
+        }
+        result["step_hbm_gbs"] = total_b * args.layers / (ms_per_step * 1e-3) / 1e9
+
+    if world == 1 and not args.no_extras:
+        extras = {}
+        other = "eager" if args.mode == "graph" else "graph"
+        r2 = make_runner(wl, other, tp_group)
+        extras[f"{other}_ms_per_step"] = timed_steps(r2, args.steps, args.warmup, 1) / args.steps * 1e3
+        extras["backend_forward_eager_ms_per_step"] = timed_steps(wl.backend_step, args.steps, args.warmup, 1) / args.steps * 1e3
+        alt = "contig" if args.table == "perm" else "perm"
+        wl.set_table(alt)
+        r3 = make_runner(wl, args.mode, tp_group)
+        extras[f"{alt}_table_ms_per_step"] = timed_steps(r3, args.steps, args.warmup, 1) / args.steps * 1e3
+        extras[f"{alt}_table_launch_us"] = kernel_event_times(wl, 5) * 1e3
+        wl.set_table(args.table)
+        result["extras"] = extras
+
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        result["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

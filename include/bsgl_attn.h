@@ -1,0 +1,162 @@
+/*
+ * bsgl_attn.h -- C ABI of libbsgl_attn.so, the MI355X (gfx950) paged-attention
+ * library that stands behind baby-sglang's attention backend.
+ *
+ * Conventions
+ *   - Every pointer marked "device" is a HIP device address owned by the caller
+ *     for the duration of the call; the library keeps no pointer after return.
+ *   - Every launch goes onto `stream` (a hipStream_t passed as void*; NULL is the
+ *     default stream).  No entry point synchronises the device, reads device
+ *     memory on the host, or allocates: callable from any host thread, with
+ *     several streams in flight, and under HIP graph capture.
+ *   - Strides are in ELEMENTS of the tensor's dtype (rows of q/k/v/out/slabs)
+ *     or of int32 (page table).  Inner dimensions are dense: a row is
+ *     n_heads * head_dim consecutive elements.
+ *   - Return value: BSGL_OK or a negative BSGL_ERR_* code; bsgl_last_error()
+ *     then returns a thread-local, NUL-terminated description.  Nothing is thrown
+ *     across the ABI.
+ *   - Page-table and slot indices are clamped inside the kernels to the table
+ *     and slab extents given here, so inconsistent metadata gives wrong
+ *     numbers, never a GPU memory fault.
+ *
+ * Reference interfaces these entry points stand behind are cited per function
+ * as file:line of the baby-sglang sources.
+ */
+#ifndef BSGL_ATTN_H
+#define BSGL_ATTN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSGL_OK 0
+#define BSGL_ERR_BAD_ARG (-1)     /* NULL pointer, negative size, misaligned row */
+#define BSGL_ERR_UNSUPPORTED (-2) /* dtype / head_dim / group size without a kernel */
+#define BSGL_ERR_HIP (-3)         /* a HIP runtime call failed */
+#define BSGL_ERR_WORKSPACE (-4)   /* workspace missing or too small */
+
+/* element types of q / k / v / out / KV slabs */
+#define BSGL_DTYPE_BF16 0
+#define BSGL_DTYPE_F16 1
+#define BSGL_DTYPE_F32 2
+
+/* decode kernel selection (bsgl_paged_decode `variant`) */
+#define BSGL_DECODE_AUTO 0
+#define BSGL_DECODE_VALU 1 /* generic: any dtype, head_dim 64/128, group <= 8 */
+#define BSGL_DECODE_MFMA 2 /* bf16/f16: QK^T on matrix cores */
+
+/* ABI version of this header (bumped on any signature change). */
+int bsgl_abi_version(void);
+
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char* bsgl_last_error(void);
+
+/*
+ * KV scatter: k_slab[loc[t]] = k_new[t], v_slab[loc[t]] = v_new[t], t < n_tok.
+ * Replaces MHATokenToKVPool.set_kv_buffer (memory_pool.py:152-171; called from
+ * attn_backend.py:20-23).  k_new / v_new rows may be strided views (v is a
+ * column slice of the merged qkv projection, qwen2.py:288); slab rows are
+ * n_kv_heads * head_dim elements, slab_row_stride apart.  A loc outside
+ * [0, n_slots) is skipped.  Rows must be 16-byte aligned.
+ */
+int bsgl_kv_scatter(void* k_slab /*device*/, void* v_slab /*device*/,
+                    int64_t slab_row_stride, int64_t n_slots,
+                    const int32_t* loc /*device, [n_tok]*/,
+                    const void* k_new /*device*/, const void* v_new /*device*/,
+                    int64_t k_row_stride, int64_t v_row_stride,
+                    int32_t n_tok, int32_t n_kv_heads, int32_t head_dim,
+                    int32_t dtype, void* stream);
+
+/*
+ * Number of sequence splits bsgl_paged_decode will use for this problem, and
+ * the workspace it needs.  Both are pure host arithmetic.
+ */
+int32_t bsgl_decode_num_splits(int32_t batch, int32_t n_kv_heads, int32_t max_context_len);
+size_t bsgl_decode_workspace_bytes(int32_t batch, int32_t n_q_heads, int32_t head_dim,
+                                   int32_t n_splits, int32_t out_is_f32);
+
+/*
+ * Paged decode attention, one query row per request.  Replaces
+ * SimpleAttentionBackend._decode_attention (attn_backend.py:112-149):
+ *   idx  = req_to_token[req_pool_indices[i], 0:seq_lens[i]]
+ *   out[i, h, :] = softmax(scale * q[i, h, :] . K[idx, h / group, :]^T) . V[idx, h / group, :]
+ * with group = n_q_heads / n_kv_heads (repeat_interleave head mapping,
+ * attn_backend.py:132-135) and no mask.  seq_lens[i] counts the token written
+ * this step; a request with seq_lens[i] <= 0 gets a zero row.
+ *
+ * out is [batch, n_q_heads * head_dim] in `out_dtype`, which is `dtype` or
+ * BSGL_DTYPE_F32 (unrounded partial results for a later merge).  lse (optional, may be NULL)
+ * receives the natural-log-sum-exp of the scaled scores, [batch, n_q_heads]
+ * fp32, which lets partial results over disjoint token sets be merged with
+ * bsgl_merge_attn_states.  n_splits comes from bsgl_decode_num_splits (or any
+ * value in [1, 64]); workspace holds bsgl_decode_workspace_bytes bytes and may
+ * be NULL when that is 0 (one split, out_dtype == dtype).
+ */
+int bsgl_paged_decode(void* out /*device*/, int64_t out_row_stride,
+                      float* lse /*device or NULL*/,
+                      const void* q /*device*/, int64_t q_row_stride,
+                      const void* k_slab /*device*/, const void* v_slab /*device*/,
+                      int64_t slab_row_stride, int64_t n_slots,
+                      const int32_t* req_to_token /*device*/, int64_t table_row_stride,
+                      int64_t table_rows, int64_t table_cols,
+                      const int64_t* req_pool_indices /*device, [batch]*/,
+                      const int64_t* seq_lens /*device, [batch]*/,
+                      int32_t batch, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim,
+                      float scale, int32_t dtype, int32_t out_dtype, int32_t n_splits,
+                      int32_t variant,
+                      void* workspace /*device*/, size_t workspace_bytes, void* stream);
+
+/*
+ * Workspace for bsgl_paged_prefill (host arithmetic).
+ */
+size_t bsgl_prefill_workspace_bytes(int32_t batch, int32_t total_q_tokens, int32_t n_q_heads,
+                                    int32_t head_dim);
+
+/*
+ * Paged prefill / extend attention.  Replaces
+ * SimpleAttentionBackend._prefill_attention (attn_backend.py:34-110): request i
+ * owns q rows [off_i, off_i + extended_lens[i]) with off_i the running sum of
+ * extended_lens over earlier requests; row r of request i attends to page-table
+ * positions 0 .. prefix_lens[i] + r (mask: col > prefix + row is -inf,
+ * attn_backend.py:74-92) of the full sequence 0 .. seq_lens[i]-1, K/V read
+ * through the page table.  Requests with extended_lens[i] == 0 own no rows.
+ * total_q_tokens is the number of rows of q and out.
+ */
+int bsgl_paged_prefill(void* out /*device*/, int64_t out_row_stride,
+                       const void* q /*device*/, int64_t q_row_stride,
+                       const void* k_slab /*device*/, const void* v_slab /*device*/,
+                       int64_t slab_row_stride, int64_t n_slots,
+                       const int32_t* req_to_token /*device*/, int64_t table_row_stride,
+                       int64_t table_rows, int64_t table_cols,
+                       const int64_t* req_pool_indices /*device, [batch]*/,
+                       const int64_t* seq_lens /*device, [batch]*/,
+                       const int64_t* prefix_lens /*device, [batch]*/,
+                       const int64_t* extended_lens /*device, [batch]*/,
+                       int32_t batch, int32_t total_q_tokens,
+                       int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim,
+                       float scale, int32_t dtype, int32_t variant,
+                       void* workspace /*device*/, size_t workspace_bytes, void* stream);
+
+/*
+ * Merge n_parts attention states computed over disjoint token sets:
+ *   w_p = exp(lse_p - max_p lse_p);  out = sum_p w_p o_p / sum_p w_p
+ * parts_o is [n_parts, rows, n_heads * head_dim] fp32 (already normalised),
+ * parts_lse is [n_parts, rows, n_heads] fp32 (natural log; -inf marks an empty
+ * part).  out is [rows, n_heads * head_dim] in `dtype`; lse_out (optional) gets
+ * the merged lse.  Used for sequence-sliced tensor parallelism, where each rank
+ * of a kv-head group holds a slice of every request's tokens; the reference
+ * has no counterpart (tp_runtime.py:10-51 only wraps the collectives).
+ */
+int bsgl_merge_attn_states(void* out /*device*/, int64_t out_row_stride,
+                           float* lse_out /*device or NULL*/,
+                           const float* parts_o /*device*/, const float* parts_lse /*device*/,
+                           int32_t n_parts, int32_t rows, int32_t n_heads, int32_t head_dim,
+                           int32_t dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BSGL_ATTN_H */

@@ -1,0 +1,378 @@
+"""Parity of the HIP path with the reference (goldens) and the float64 oracle.
+
+Everything here runs on a real MI355X and goes through the product API
+(pools -> SimplifiedForwardBatch -> SimpleAttentionBackend.forward), i.e. through
+the C ABI of libbsgl_attn.so.  Tolerances (kernel output in dtype vs float64
+oracle on the same rounded inputs):
+  fp32  rtol 1e-4 atol 1e-5
+  fp16  rtol 1e-3 atol 1e-3   (the bar the task states)
+  bf16  rtol 8e-3 atol 2e-3   (bf16 output rounding is 2^-9 relative)
+KV rows written by the scatter kernel are compared bit for bit.
+"""
+import math
+import types
+
+import pytest
+import torch
+
+from conftest import golden_names, golden_new_rows, load_golden
+from oracle import attn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = {
+    torch.float32: dict(rtol=1e-4, atol=1e-5),
+    torch.float16: dict(rtol=1e-3, atol=1e-3),
+    torch.bfloat16: dict(rtol=8e-3, atol=2e-3),
+}
+
+
+def assert_close(got, want64, dtype, what=""):
+    got64 = got.detach().double().cpu()
+    tol = TOL[dtype]
+    ok = torch.isclose(got64, want64, **tol)
+    if not bool(ok.all()):
+        err = (got64 - want64).abs()
+        bad = int((~ok).sum())
+        raise AssertionError(
+            f"{what}: {bad}/{ok.numel()} elements outside rtol={tol['rtol']} atol={tol['atol']}; "
+            f"max abs err {err.max().item():.3e} at {int(err.argmax())}"
+        )
+
+
+def product_forward(case, dev, layout="interleaved", variant=None):
+    """Run one golden case through the product backend on the GPU."""
+    import baby_sglang_amd as pkg
+
+    hkv, dim = case["n_kv_heads"], case["head_dim"]
+    dtype = case["q"].dtype
+    n_slots = case["k_slab"].shape[0]
+    r2t = pkg.ReqToTokenPool(case["req_to_token"].shape[0], case["req_to_token"].shape[1], str(dev))
+    r2t.req_to_token.copy_(case["req_to_token"])
+    kv = pkg.MHATokenToKVPool(n_slots - 1, dtype, hkv, dim, layer_num=3, device=str(dev), kv_layout=layout)
+    layer_id = 2
+    kv.k_buffer[layer_id].copy_(case["k_slab"])
+    kv.v_buffer[layer_id].copy_(case["v_slab"])
+    q, k, v = (t.to(dev) for t in (case["q"], case["k"], case["qkv"]))
+    v = v[:, case["v_col0"] :].view(v.shape[0], hkv, dim)  # strided view, as in the model
+    common = dict(
+        input_ids=torch.zeros(q.shape[0], dtype=torch.int64, device=dev),
+        req_pool_indices=case["req_pool_indices"].to(dev), seq_lens=case["seq_lens"].to(dev),
+        out_cache_loc=case["out_cache_loc"].to(dev), req_to_token_pool=r2t, token_to_kv_pool=kv,
+    )
+    if case["kind"] == "prefill":
+        fb = pkg.SimplifiedForwardBatch.create_prefill_batch(prefix_lens=case["prefix_lens"].to(dev), **common)
+    else:
+        fb = pkg.SimplifiedForwardBatch.create_decode_batch(**common)
+    layer = types.SimpleNamespace(layer_id=layer_id, scaling=dim**-0.5)
+    old = pkg.SimpleAttentionBackend.decode_variant
+    if variant is not None:
+        pkg.SimpleAttentionBackend.decode_variant = variant
+    try:
+        out = pkg.SimpleAttentionBackend.forward(q, k, v, layer, fb, save_kv_cache=case["save_kv_cache"])
+    finally:
+        pkg.SimpleAttentionBackend.decode_variant = old
+    torch.cuda.synchronize()
+    return out, kv.k_buffer[layer_id], kv.v_buffer[layer_id]
+
+
+def oracle_exact(case):
+    q, k, v = golden_new_rows(case)
+    k_slab, v_slab = case["k_slab"].clone(), case["v_slab"].clone()
+    if case["save_kv_cache"]:
+        orc.kv_scatter_ref(k_slab, v_slab, case["out_cache_loc"], k, v)
+    args = (q, k_slab, v_slab, case["req_to_token"], case["req_pool_indices"], case["seq_lens"])
+    if case["kind"] == "prefill":
+        return orc.prefill_exact(*args, case["prefix_lens"], case["extended_lens"]), k_slab, v_slab
+    return orc.decode_exact(*args), k_slab, v_slab
+
+
+@pytest.mark.parametrize("layout", ["interleaved", "split"])
+@pytest.mark.parametrize("name", golden_names("decode_") + golden_names("prefill_"))
+def test_golden_cases(gpu, name, layout):
+    case = load_golden(name)
+    dtype = case["q"].dtype
+    out, k_slab, v_slab = product_forward(case, gpu, layout)
+    want, k_want, v_want = oracle_exact(case)
+    assert out.dtype == dtype and tuple(out.shape) == tuple(case["out"].shape)
+    assert_close(out, want, dtype, f"{name} vs float64 oracle")
+    # and directly against what the reference produced (its own rounding included)
+    ref_tol = {torch.float32: 1e-5, torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dtype]
+    assert (out.double().cpu() - case["out"].double()).abs().max().item() <= ref_tol
+    # KV write: bit exact, untouched slots untouched
+    assert torch.equal(k_slab.cpu(), k_want) and torch.equal(v_slab.cpu(), v_want)
+
+
+def test_scheduler_trace_on_gpu(gpu):
+    """Replay the reference scheduler's ForwardBatch sequence (prefix reuse,
+    recycled slots) through the product backend, one persistent pool."""
+    import baby_sglang_amd as pkg
+
+    tr = load_golden("sched_trace")
+    hkv, dim = tr["n_kv_heads"], tr["head_dim"]
+    first = tr["batches"][0]
+    n_slots = first["k_slab_after"].shape[0]
+    r2t = pkg.ReqToTokenPool(first["req_to_token"].shape[0], first["req_to_token"].shape[1], str(gpu))
+    kv = pkg.MHATokenToKVPool(n_slots - 1, first["q"].dtype, hkv, dim, layer_num=1, device=str(gpu))
+    kv.k_buffer[0].zero_()
+    kv.v_buffer[0].zero_()
+    layer = types.SimpleNamespace(layer_id=0, scaling=dim**-0.5)
+    for step, b in enumerate(tr["batches"]):
+        r2t.req_to_token.copy_(b["req_to_token"])
+        common = dict(
+            input_ids=torch.zeros(b["q"].shape[0], dtype=torch.int64, device=gpu),
+            req_pool_indices=b["req_pool_indices"].to(gpu), seq_lens=b["seq_lens"].to(gpu),
+            out_cache_loc=b["out_cache_loc"].to(gpu), req_to_token_pool=r2t, token_to_kv_pool=kv,
+        )
+        if b["is_prefill"]:
+            fb = pkg.SimplifiedForwardBatch.create_prefill_batch(prefix_lens=b["prefix_lens"].to(gpu), **common)
+        else:
+            fb = pkg.SimplifiedForwardBatch.create_decode_batch(**common)
+        out = pkg.SimpleAttentionBackend.forward(b["q"].to(gpu), b["k"].to(gpu), b["v"].to(gpu), layer, fb)
+        assert (out.double().cpu() - b["out"].double()).abs().max().item() <= 1e-5, f"batch {step}"
+        # every slot the scheduler has handed out so far holds the reference's bytes
+        live = b["req_to_token"][b["req_pool_indices"]].flatten().long().unique()
+        assert torch.equal(kv.k_buffer[0].cpu()[live], b["k_slab_after"][live]), f"batch {step}"
+        assert torch.equal(kv.v_buffer[0].cpu()[live], b["v_slab_after"][live]), f"batch {step}"
+
+
+# ----------------------------------------------------------------------------- seeded random cases
+def random_decode_problem(dev, dtype, hq, hkv, dim, seq_lens, seed, layout="interleaved", slack=16):
+    import baby_sglang_amd as pkg
+
+    gen = torch.Generator().manual_seed(seed)
+    batch = len(seq_lens)
+    size = sum(seq_lens) + slack
+    max_ctx = max(max(seq_lens), 1) + 5
+    table = torch.zeros((batch + 1, max_ctx), dtype=torch.int32)
+    perm = (torch.randperm(size, generator=gen) + 1).to(torch.int32)
+    rows = torch.randperm(batch + 1, generator=gen)[:batch]
+    used = 0
+    for i, n in enumerate(seq_lens):
+        table[rows[i], :n] = perm[used : used + n]
+        used += n
+    k_slab = torch.randn((size + 1, hkv, dim), generator=gen).to(dtype)
+    v_slab = torch.randn((size + 1, hkv, dim), generator=gen).to(dtype)
+    q = torch.randn((batch, hq, dim), generator=gen).to(dtype)
+    r2t = pkg.ReqToTokenPool(batch + 1, max_ctx, str(dev))
+    r2t.req_to_token.copy_(table)
+    kv = pkg.MHATokenToKVPool(size, dtype, hkv, dim, layer_num=1, device=str(dev), kv_layout=layout)
+    kv.k_buffer[0].copy_(k_slab)
+    kv.v_buffer[0].copy_(v_slab)
+    cpu = dict(q=q, k_slab=k_slab, v_slab=v_slab, req_to_token=table, req_pool_indices=rows.long(),
+               seq_lens=torch.tensor(seq_lens, dtype=torch.int64))
+    return cpu, r2t, kv
+
+
+@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("hq,hkv,dim", [(12, 2, 128), (14, 2, 64), (28, 4, 128), (4, 4, 64), (8, 1, 128), (6, 1, 128)])
+def test_decode_random_ragged(gpu, dtype, hq, hkv, dim, variant):
+    from baby_sglang_amd import _hip
+
+    seq_lens = [1, 2, 63, 64, 65, 300, 1025, 7, 128, 129, 511]
+    cpu, r2t, kv = random_decode_problem(gpu, dtype, hq, hkv, dim, seq_lens, seed=hq * 1000 + dim)
+    want, want_lse = orc.decode_exact(cpu["q"], cpu["k_slab"], cpu["v_slab"], cpu["req_to_token"],
+                                      cpu["req_pool_indices"], cpu["seq_lens"], return_lse=True)
+    k_slab, v_slab = kv.get_kv_buffer(0)
+    for n_splits in (1, 3, 16):
+        lse = torch.empty((len(seq_lens), hq), dtype=torch.float32, device=gpu)
+        out = _hip.paged_decode(cpu["q"].to(gpu), k_slab, v_slab, r2t.req_to_token,
+                                cpu["req_pool_indices"].to(gpu), cpu["seq_lens"].to(gpu),
+                                n_splits=n_splits, variant=variant, lse=lse)
+        torch.cuda.synchronize()
+        assert_close(out, want, dtype, f"decode splits={n_splits}")
+        assert torch.allclose(lse.double().cpu(), want_lse, rtol=1e-4, atol=2e-3 if dtype != torch.float32 else 1e-4)
+
+
+def test_decode_empty_and_zero_length(gpu):
+    from baby_sglang_amd import _hip
+
+    cpu, r2t, kv = random_decode_problem(gpu, torch.bfloat16, 12, 2, 128, [5, 0, 9], seed=7)
+    k_slab, v_slab = kv.get_kv_buffer(0)
+    out = _hip.paged_decode(cpu["q"].to(gpu), k_slab, v_slab, r2t.req_to_token,
+                            cpu["req_pool_indices"].to(gpu), cpu["seq_lens"].to(gpu))
+    want = orc.decode_exact(cpu["q"], cpu["k_slab"], cpu["v_slab"], cpu["req_to_token"],
+                            cpu["req_pool_indices"], cpu["seq_lens"])
+    assert_close(out, want, torch.bfloat16, "zero-length request")
+    assert float(out[1].abs().max()) == 0.0
+    empty = _hip.paged_decode(cpu["q"][:0].to(gpu), k_slab, v_slab, r2t.req_to_token,
+                              cpu["req_pool_indices"][:0].to(gpu), cpu["seq_lens"][:0].to(gpu))
+    assert tuple(empty.shape) == (0, 12 * 128)
+
+
+def test_decode_softmax_spike(gpu):
+    """A key that dominates late in the sequence forces the running-max rescale
+    path in every split and wave (large positive score after many small ones)."""
+    from baby_sglang_amd import _hip
+
+    seq = 700
+    cpu, r2t, kv = random_decode_problem(gpu, torch.bfloat16, 12, 2, 128, [seq, seq], seed=11)
+    for pos in (seq - 1, 333):
+        slot = int(cpu["req_to_token"][cpu["req_pool_indices"][0], pos])
+        cpu["k_slab"][slot] = (cpu["q"][0, ::6] * 3.0).to(torch.bfloat16)  # aligned with q heads 0 and 6
+    kv.k_buffer[0].copy_(cpu["k_slab"])
+    want = orc.decode_exact(cpu["q"], cpu["k_slab"], cpu["v_slab"], cpu["req_to_token"],
+                            cpu["req_pool_indices"], cpu["seq_lens"])
+    k_slab, v_slab = kv.get_kv_buffer(0)
+    for variant in (1, 0):
+        for n_splits in (1, 5):
+            out = _hip.paged_decode(cpu["q"].to(gpu), k_slab, v_slab, r2t.req_to_token,
+                                    cpu["req_pool_indices"].to(gpu), cpu["seq_lens"].to(gpu),
+                                    n_splits=n_splits, variant=variant)
+            assert_close(out, want, torch.bfloat16, f"spike variant={variant} splits={n_splits}")
+
+
+def test_bad_metadata_never_faults(gpu):
+    """Out-of-range slots, rows and lengths are clamped: wrong numbers, no fault."""
+    from baby_sglang_amd import _hip
+
+    cpu, r2t, kv = random_decode_problem(gpu, torch.float16, 12, 2, 128, [40, 40], seed=3)
+    r2t.req_to_token[:, 3] = 2**30
+    r2t.req_to_token[:, 4] = -5
+    k_slab, v_slab = kv.get_kv_buffer(0)
+    out = _hip.paged_decode(cpu["q"].to(gpu), k_slab, v_slab, r2t.req_to_token,
+                            torch.tensor([99, -3], device=gpu), torch.tensor([10**6, 40], device=gpu))
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out.float()).all())
+    loc = torch.tensor([1, 10**6, -1], dtype=torch.int32, device=gpu)
+    rows = torch.ones((3, 2, 128), dtype=torch.float16, device=gpu)
+    before = k_slab.clone()
+    _hip.kv_scatter(k_slab, v_slab, loc, rows, rows)
+    torch.cuda.synchronize()
+    assert float(k_slab[1].float().min()) == 1.0
+    assert torch.equal(k_slab[2:], before[2:]) and torch.equal(k_slab[0], before[0])
+
+
+def test_errors_map_to_python_exceptions(gpu):
+    from baby_sglang_amd import _hip
+
+    cpu, r2t, kv = random_decode_problem(gpu, torch.float16, 12, 2, 128, [8], seed=5)
+    k_slab, v_slab = kv.get_kv_buffer(0)
+    with pytest.raises(NotImplementedError):  # head_dim 96 has no kernel
+        _hip.paged_decode(torch.zeros((1, 2, 96), dtype=torch.float16, device=gpu),
+                          torch.zeros((4, 2, 96), dtype=torch.float16, device=gpu),
+                          torch.zeros((4, 2, 96), dtype=torch.float16, device=gpu),
+                          r2t.req_to_token, torch.zeros(1, dtype=torch.int64, device=gpu),
+                          torch.ones(1, dtype=torch.int64, device=gpu))
+    with pytest.raises(ValueError):  # dtype mismatch between q and slabs
+        _hip.paged_decode(cpu["q"].to(gpu).float(), k_slab, v_slab, r2t.req_to_token,
+                          cpu["req_pool_indices"].to(gpu), cpu["seq_lens"].to(gpu))
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        _hip.paged_decode(cpu["q"], k_slab, v_slab, r2t.req_to_token,
+                          cpu["req_pool_indices"].to(gpu), cpu["seq_lens"].to(gpu))
+
+
+def test_merge_attn_states(gpu):
+    from baby_sglang_amd import _hip
+
+    gen = torch.Generator().manual_seed(0)
+    parts_o = torch.randn((3, 5, 12, 128), generator=gen)
+    parts_lse = torch.randn((3, 5, 12), generator=gen) * 4
+    parts_lse[1, 2] = float("-inf")  # an empty part
+    parts_lse[:, 4, 3] = float("-inf")  # nothing anywhere -> zero row
+    want, want_lse = orc.merge_states_exact(parts_o, parts_lse)
+    for dtype in (torch.bfloat16, torch.float16, torch.float32):
+        lse = torch.empty((5, 12), dtype=torch.float32, device=gpu)
+        out = _hip.merge_attn_states(parts_o.to(gpu), parts_lse.to(gpu), dtype, lse_out=lse)
+        assert_close(out, want, dtype, "merge")
+        assert torch.allclose(lse.double().cpu(), want_lse, rtol=1e-5, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------- full-size properties
+def test_full_size_properties(gpu):
+    """Qwen2.5-1.5B shapes, batch 64, seq 2048, random-permutation page table:
+    split-count invariance, page-permutation invariance, constant-V identity,
+    half/half merge, and four requests checked against the float64 oracle."""
+    from baby_sglang_amd import _hip
+
+    B, S, hq, hkv, dim = 64, 2048, 12, 2, 128
+    dtype = torch.bfloat16
+    gen = torch.Generator(device=gpu).manual_seed(0)
+    n_slots = B * S + 1
+    k_slab = torch.randn((n_slots, hkv, dim), generator=gen, device=gpu, dtype=torch.float32).to(dtype)
+    v_slab = torch.randn((n_slots, hkv, dim), generator=gen, device=gpu, dtype=torch.float32).to(dtype)
+    q = torch.randn((B, hq, dim), generator=gen, device=gpu, dtype=torch.float32).to(dtype)
+    perm = torch.randperm(B * S, generator=gen, device=gpu).to(torch.int32) + 1
+    table = torch.zeros((B, 4096), dtype=torch.int32, device=gpu)
+    table[:, :S] = perm.view(B, S)
+    rows = torch.arange(B, device=gpu)
+    seq = torch.full((B,), S, dtype=torch.int64, device=gpu)
+
+    base = _hip.paged_decode(q, k_slab, v_slab, table, rows, seq, n_splits=1, variant=1).float()
+    # (a) any split count / kernel variant gives the same rows (fp32 partials, one final rounding)
+    for variant in (1, 0):
+        for n_splits in (4, 16, 37):
+            other = _hip.paged_decode(q, k_slab, v_slab, table, rows, seq, n_splits=n_splits, variant=variant).float()
+            assert torch.allclose(other, base, rtol=8e-3, atol=2e-3), (variant, n_splits)
+    # (b) attention is invariant under a permutation of a request's pages
+    shuffled = table.clone()
+    shuffled[:, :S] = table[:, torch.randperm(S, generator=gen, device=gpu)]
+    other = _hip.paged_decode(q, k_slab, v_slab, shuffled, rows, seq).float()
+    assert torch.allclose(other, base, rtol=8e-3, atol=2e-3)
+    # (c) constant V rows -> the output is that constant, whatever the scores are
+    const = _hip.paged_decode(q, k_slab, torch.full_like(v_slab, 0.75), table, rows, seq).float()
+    assert torch.allclose(const, torch.full_like(const, 0.75), rtol=0, atol=4e-3)
+    # (d) two halves merged == whole
+    parts_o, parts_lse = [], []
+    for half in range(2):
+        t = torch.zeros_like(table)
+        t[:, : S // 2] = table[:, half * (S // 2) : (half + 1) * (S // 2)]
+        lse = torch.empty((B, hq), dtype=torch.float32, device=gpu)
+        o = _hip.paged_decode(q, k_slab, v_slab, t, rows, seq // 2, lse=lse, out_dtype=torch.float32)
+        parts_o.append(o.view(B, hq, dim))
+        parts_lse.append(lse)
+    merged = _hip.merge_attn_states(torch.stack(parts_o), torch.stack(parts_lse), dtype).float()
+    assert torch.allclose(merged, base, rtol=8e-3, atol=2e-3)
+    # (e) float64 oracle on four requests
+    pick = [0, 17, 42, 63]
+    want = orc.decode_exact(q[pick].cpu(), k_slab.cpu(), v_slab.cpu(), table.cpu(), rows[pick].cpu(), seq[pick].cpu())
+    got = _hip.paged_decode(q, k_slab, v_slab, table, rows, seq)
+    assert_close(got[pick], want, dtype, "full size vs oracle")
+
+
+def test_prefill_random(gpu):
+    """Extend batches: ragged lengths, prefixes, an ext==0 request, 7B head shape."""
+    import baby_sglang_amd as pkg
+    from baby_sglang_amd import _hip
+
+    for dtype, (hq, hkv, dim) in [(torch.bfloat16, (12, 2, 128)), (torch.float16, (28, 4, 128)), (torch.float32, (14, 2, 64))]:
+        seq_lens = [150, 64, 33, 257, 1]
+        prefix_lens = [20, 0, 33, 128, 0]
+        cpu, r2t, kv = random_decode_problem(gpu, dtype, hq, hkv, dim, seq_lens, seed=dim + hq)
+        ext = [s - p for s, p in zip(seq_lens, prefix_lens)]
+        gen = torch.Generator().manual_seed(1)
+        q = torch.randn((sum(ext), hq, dim), generator=gen).to(dtype)
+        pl, el = torch.tensor(prefix_lens), torch.tensor(ext)
+        want = orc.prefill_exact(q, cpu["k_slab"], cpu["v_slab"], cpu["req_to_token"],
+                                 cpu["req_pool_indices"], cpu["seq_lens"], pl, el)
+        k_slab, v_slab = kv.get_kv_buffer(0)
+        out = _hip.paged_prefill(q.to(gpu), k_slab, v_slab, r2t.req_to_token, cpu["req_pool_indices"].to(gpu),
+                                 cpu["seq_lens"].to(gpu), pl.to(gpu), el.to(gpu))
+        assert_close(out, want, dtype, f"prefill {dtype}")
+
+
+def test_side_stream_and_thread(gpu):
+    """The reference calls its backend from a worker thread inside a side stream
+    (overlap_worker.py:104-127); results must not depend on either."""
+    import threading
+
+    from baby_sglang_amd import _hip
+
+    cpu, r2t, kv = random_decode_problem(gpu, torch.bfloat16, 12, 2, 128, [200, 31, 77], seed=21)
+    k_slab, v_slab = kv.get_kv_buffer(0)
+    args = (cpu["q"].to(gpu), k_slab, v_slab, r2t.req_to_token, cpu["req_pool_indices"].to(gpu), cpu["seq_lens"].to(gpu))
+    base = _hip.paged_decode(*args)
+    torch.cuda.synchronize()
+    box = {}
+
+    def work():
+        s = torch.cuda.Stream(device=gpu)
+        with torch.cuda.stream(s):
+            box["out"] = _hip.paged_decode(*args)
+        s.synchronize()
+
+    t = threading.Thread(target=work)
+    t.start()
+    t.join()
+    assert torch.equal(box["out"], base)

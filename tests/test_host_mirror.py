@@ -1,0 +1,129 @@
+"""Host-side mirror of the reference interface against traces captured from the
+reference (CPU only): allocator order, page-table writes, batch descriptors."""
+import pytest
+import torch
+
+from conftest import golden_names, load_golden
+from baby_sglang_amd import MHATokenToKVPool, ReqToTokenPool, SimplifiedForwardBatch
+
+
+def test_kv_pool_alloc_free_trace():
+    tr = load_golden("pools")
+    pool = MHATokenToKVPool(size=12, dtype=torch.float16, head_num=1, head_dim=8, layer_num=1, device="cpu")
+    shape, dtype, free_dtype = tr["kv_shapes"]
+    assert tuple(pool.k_buffer[0].shape) == tuple(shape) and tuple(pool.v_buffer[0].shape) == tuple(shape)
+    assert str(pool.k_buffer[0].dtype) == dtype and str(pool.free_slots.dtype) == free_dtype
+    for op, n, val in tr["kv_ops"]:
+        if op == "available":
+            assert pool.available_size() == int(val[0])
+        elif op == "alloc":
+            got = pool.alloc(n)
+            assert got.dtype == val.dtype and torch.equal(got, val)
+        elif op == "alloc_none":
+            assert (pool.alloc(n) is None) == bool(val[0])
+        elif op == "free":
+            pool.free(val)
+        elif op == "clear":
+            pool.clear()
+            assert torch.equal(pool.free_slots, val)
+        else:
+            raise AssertionError(op)
+
+
+def test_req_pool_trace():
+    tr = load_golden("pools")
+    pool = ReqToTokenPool(size=5, max_context_len=7, device="cpu")
+    assert pool.req_to_token.dtype == torch.int32 and tuple(pool.req_to_token.shape) == (5, 7)
+    first = True
+    for op, n, val in tr["req_ops"]:
+        if op == "alloc":
+            assert pool.alloc(n) == val
+        elif op == "alloc_none":
+            assert (pool.alloc(n) is None) == val
+        elif op == "free":
+            # the trace frees one id as an int first, then a list
+            pool.free(val[0] if first and len(val) == 1 else val)
+            first = False
+        elif op == "available":
+            assert pool.available_size() == val
+        elif op == "table":
+            pool.write(torch.tensor([1, 3]), torch.arange(14, dtype=torch.int32).view(2, 7))
+            pool.write((2, slice(1, 4)), torch.tensor([9, 8, 7], dtype=torch.int32))
+            assert torch.equal(pool.req_to_token, val)
+        elif op == "clear":
+            pool.clear()
+            assert pool.free_slots == val
+        else:
+            raise AssertionError(op)
+
+
+@pytest.mark.parametrize("layout", ["interleaved", "split"])
+def test_kv_pool_layouts(layout):
+    pool = MHATokenToKVPool(size=9, dtype=torch.bfloat16, head_num=2, head_dim=64, layer_num=3, device="cpu", kv_layout=layout)
+    k, v = pool.get_kv_buffer(2)
+    assert tuple(k.shape) == tuple(v.shape) == (10, 2, 64)
+    assert k.stride(2) == 1 and k.stride(1) == 64 and k.stride(0) == v.stride(0) == pool.row_stride
+    assert pool.row_stride == (256 if layout == "interleaved" else 128)
+    k.fill_(1.0)
+    v.fill_(2.0)
+    assert float(pool.get_key_buffer(2).float().mean()) == 1.0 and float(pool.get_value_buffer(2).float().mean()) == 2.0
+    with pytest.raises(ValueError):
+        MHATokenToKVPool(size=1, dtype=torch.float16, head_num=1, head_dim=8, layer_num=1, device="cpu", kv_layout="x")
+
+
+def test_fp8_pool_refuses_reads_and_writes():
+    pool = MHATokenToKVPool(size=4, dtype=torch.float8_e4m3fn, head_num=1, head_dim=16, layer_num=1, device="cpu")
+    assert pool.store_dtype == torch.uint8
+    with pytest.raises(NotImplementedError):
+        pool.get_kv_buffer(0)
+    with pytest.raises(NotImplementedError):
+        x = torch.zeros((1, 1, 16), dtype=torch.float8_e4m3fn)
+        pool.set_kv_buffer(0, torch.tensor([1], dtype=torch.int32), x, x)
+
+
+def test_set_kv_buffer_has_no_cpu_path():
+    pool = MHATokenToKVPool(size=4, dtype=torch.float16, head_num=1, head_dim=16, layer_num=1, device="cpu")
+    x = torch.zeros((1, 1, 16), dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        pool.set_kv_buffer(0, torch.tensor([1], dtype=torch.int32), x, x)
+
+
+@pytest.mark.parametrize("name", golden_names("prefill_"))
+def test_prefill_batch_descriptor(name):
+    case = load_golden(name)
+    fb = SimplifiedForwardBatch.create_prefill_batch(
+        input_ids=torch.zeros(len(case["out_cache_loc"]), dtype=torch.int64),
+        req_pool_indices=case["req_pool_indices"], seq_lens=case["seq_lens"],
+        out_cache_loc=case["out_cache_loc"], req_to_token_pool=None, token_to_kv_pool=None,
+        prefix_lens=case["prefix_lens"],
+    )
+    assert fb.is_prefill and fb.batch_size == len(case["seq_lens"])
+    assert fb.extended_lens.dtype == torch.int64 and torch.equal(fb.extended_lens, case["extended_lens"])
+    assert fb.positions.dtype == torch.int64 and torch.equal(fb.positions, case["positions"])
+
+
+@pytest.mark.parametrize("name", golden_names("decode_"))
+def test_decode_batch_descriptor(name):
+    case = load_golden(name)
+    fb = SimplifiedForwardBatch.create_decode_batch(
+        input_ids=torch.zeros(len(case["seq_lens"]), dtype=torch.int64),
+        req_pool_indices=case["req_pool_indices"], seq_lens=case["seq_lens"],
+        out_cache_loc=case["out_cache_loc"], req_to_token_pool=None, token_to_kv_pool=None,
+    )
+    assert not fb.is_prefill and fb.prefix_lens is None and fb.extended_lens is None
+    assert torch.equal(fb.positions, case["positions"])
+
+
+def test_scheduler_trace_descriptors():
+    tr = load_golden("sched_trace")
+    for b in tr["batches"]:
+        if b["is_prefill"]:
+            fb = SimplifiedForwardBatch.create_prefill_batch(
+                torch.zeros(len(b["out_cache_loc"]), dtype=torch.int64), b["req_pool_indices"], b["seq_lens"],
+                b["out_cache_loc"], None, None, b["prefix_lens"])
+            assert torch.equal(fb.extended_lens, b["extended_lens"])
+        else:
+            fb = SimplifiedForwardBatch.create_decode_batch(
+                torch.zeros(len(b["seq_lens"]), dtype=torch.int64), b["req_pool_indices"], b["seq_lens"],
+                b["out_cache_loc"], None, None)
+        assert torch.equal(fb.positions, b["positions"])
