@@ -43,9 +43,10 @@ template <> struct Elem<bf16_tag> {
     return acc;
   }
   __device__ static __forceinline__ uint32_t pack2(float lo, float hi) {
-    // round-to-nearest-even; the plain cast keeps NaN a NaN
-    __hip_bfloat16 a = __float2bfloat16(lo), b = __float2bfloat16(hi);
-    return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+    // round-to-nearest-even, NaN stays NaN; one v_cvt_pk_bf16_f32
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    const f32x2_t f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
   }
   __device__ static __forceinline__ uint4 pack(const float (&f)[8]) {
     return make_uint4(pack2(f[0], f[1]), pack2(f[2], f[3]), pack2(f[4], f[5]), pack2(f[6], f[7]));

@@ -275,7 +275,8 @@ int bsgl_merge_attn_states(void* out, int64_t out_row_stride, float* lse_out, co
                            const float* parts_lse, int32_t n_parts, int32_t rows, int32_t n_heads,
                            int32_t head_dim, int32_t dtype, void* stream) {
   if (int rc = check_dtype(dtype)) return rc;
-  if (rows < 0 || n_parts < 1 || n_heads <= 0) return fail(BSGL_ERR_BAD_ARG, "rows < 0, n_parts < 1 or n_heads <= 0");
+  if (rows < 0 || n_parts < 1 || n_parts > 64 || n_heads <= 0)
+    return fail(BSGL_ERR_BAD_ARG, "rows < 0, n_parts outside [1, 64] or n_heads <= 0");
   if (rows == 0) return BSGL_OK;
   if (head_dim != 64 && head_dim != 128) return fail(BSGL_ERR_UNSUPPORTED, "head_dim must be 64 or 128");
   if (!out || !parts_o || !parts_lse) return fail(BSGL_ERR_BAD_ARG, "null device pointer (out/parts_o/parts_lse)");

@@ -1,19 +1,432 @@
-// Matrix-core paged decode attention for gfx950 (bf16 / f16).
+// Matrix-core paged decode attention for gfx950 (bf16 / f16, head_dim 128).
+//
+// One workgroup = ONE wave = one (query row, kv-head group, sequence split).
+// The wave streams its tokens' K and V rows from the paged slabs into a private
+// LDS ring with LDS-DMA loads (global_load_lds_dwordx4: no VGPRs, per-lane
+// source address = page-table gather, 1 KiB of whole slab rows per
+// instruction), keeps NSTAGE-1 tiles of 16 tokens in flight behind a counted
+// s_waitcnt, and consumes each tile with matrix instructions:
+//
+//   S^T[token][q]  = K[token][:] . Q^T          4 x v_mfma_f32_16x16x32 (A = K rows
+//                    (ds_read_b128), B = Q^T held in registers, q heads padded to 16)
+//   online softmax   in base 2 on the accumulator layout: a lane owns one q head
+//                    and 4 tokens; max / sum across the 4 lane groups
+//   O[q][d]       += P[q][token] . V[token][d]   8 x v_mfma_f32_16x16x16 (A = P packed
+//                    from the accumulator as is, B = V through ds_read_b64_tr_b16)
+//
+// so the vector ALU only does the softmax and neither K nor V is ever copied
+// per q head (the reference repeats them, attn_backend.py:132-135).  There is
+// no barrier anywhere: a wave only reads LDS bytes its own DMA wrote.
+//
+// LDS image of a tile: 16 token records of HPT * 512 B: [K head 0..HPT-1 | V head
+// 0..HPT-1], 256 B per head row.  Token t of the tile sits in record
+// rec(t) = t with bits 2 and 3 swapped, and 16-byte chunk c of a row is stored at
+// chunk c ^ xr(rec), xr(r) = ((r & 3) << 2) | ((r >> 2) & 3): with that the
+// transposed V reads are bank-conflict free and the K row reads 2-way.  The DMA
+// destination is linear in the lane, so the swizzle is applied to each lane's
+// SOURCE address.
 #include "bsgl_device.h"
 #include "bsgl_launch.h"
 
 namespace bsgl {
 
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+
+constexpr int kTile = 16;        // tokens per tile (= MFMA M of the score product)
+constexpr int kSlotBlock = 512;  // page-table entries staged in LDS at a time
+
+template <typename Tag> struct Mma;
+template <> struct Mma<bf16_tag> {
+  __device__ static __forceinline__ f32x4 qk(const uint4& k, const uint4& q, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, k), __builtin_bit_cast(bf16x8_t, q), c, 0, 0, 0);
+  }
+  __device__ static __forceinline__ f32x4 pv(const uint2& p, const s16x4_t& v, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, p), v, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<f16_tag> {
+  __device__ static __forceinline__ f32x4 qk(const uint4& k, const uint4& q, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, k), __builtin_bit_cast(f16x8_t, q), c, 0, 0, 0);
+  }
+  __device__ static __forceinline__ f32x4 pv(const uint2& p, const s16x4_t& v, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_t, p), __builtin_bit_cast(f16x4_t, v), c, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ constexpr int rec_of_token(int t) { return (t & 3) | ((t & 4) << 1) | ((t & 8) >> 1); }
+__device__ __forceinline__ constexpr int xr_of_rec(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
+
+// One LDS-DMA instruction: 64 lanes x 16 B from per-lane global addresses to
+// LDS bytes [lds_dst, lds_dst + 1024), lane-linear.  M0 carries the LDS address
+// and is restored, the compiler does not see the LDS write or count the load:
+// completion is awaited with dma_wait<N>() below.
+template <bool NT>
+__device__ __forceinline__ void dma_1k(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  if constexpr (NT) {  // non-temporal: K/V bytes are read once per step
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off nt\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+  } else {
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+  }
+}
+
+// max / sum over the four lanes {l, l^16, l^32, l^48} (the lane groups that share a
+// q head), every lane receiving the result: two half exchanges on the vector ALU.
+// v_permlane32_swap a, b: lanes 32-63 of a trade places with lanes 0-31 of b;
+// v_permlane16_swap a, b: the odd 16-lane rows of a with the even rows of b.
+// Written in assembly with both registers as read-write operands: with
+// __builtin_amdgcn_permlane{16,32}_swap hipcc (ROCm 7.2) folds the two results of
+// one call into the same register in expressions such as max(r[0], r[1]).
+// s_nop 1 = the two wait states a VALU write needs before the swap reads it.
+__device__ __forceinline__ void swap32(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap16(float& a, float& b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float quad_group_max(float x) {
+  float a = x, b = x;
+  swap32(a, b);
+  a = fmaxf(a, b);
+  b = a;
+  swap16(a, b);
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float quad_group_sum(float x) {
+  float a = x, b = x;
+  swap32(a, b);
+  a = a + b;
+  b = a;
+  swap16(a, b);
+  return a + b;
+}
+
+// wait until at most N of this wave's vector-memory operations are outstanding
+template <int N> __device__ __forceinline__ void dma_wait() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename Tag, int HPT, int NSTAGE, bool NT>
+__global__ __launch_bounds__(64) void decode_mfma_kernel(DecodeArgs a) {
+  using E = Elem<Tag>;
+  constexpr int D = 128;
+  constexpr int REC = HPT * 512;                // bytes of one token record in LDS
+  constexpr int TILE_BYTES = kTile * REC;
+  constexpr int DMA_PER_TILE = TILE_BYTES / 1024;
+  constexpr int TOK_PER_DMA = 1024 / REC;       // 1 (HPT 2) or 2 (HPT 1)
+  constexpr int RING = NSTAGE * TILE_BYTES;
+  static_assert(HPT == 1 || HPT == 2, "");
+  static_assert((NSTAGE - 1) * DMA_PER_TILE < 64, "vmcnt is a 6-bit counter");
+
+  __shared__ __attribute__((aligned(1024))) char smem[RING + kSlotBlock * 4];
+  int32_t* s_slots = (int32_t*)(smem + RING);
+  const uint32_t lds_ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+  const int lane = threadIdx.x;
+  const int row = blockIdx.x;
+  const int head0 = blockIdx.y * HPT;
+  const int split = blockIdx.z;
+  const int G = a.n_q_heads / a.n_kv_heads;
+  const int lq = lane & 15;   // q head (column of S^T / row of O) or d column
+  const int lg = lane >> 4;   // lane group
+
+  // ---- this row's token range (multiples of the tile so splits start on tiles) ----
+  int64_t req = a.req_idx[row];
+  req = req < 0 ? 0 : (req >= a.kv.table_rows ? a.kv.table_rows - 1 : req);
+  const int64_t seq64 = a.seq_lens[row];
+  const int seq = (int)(seq64 < 0 ? 0 : (seq64 > a.kv.table_cols ? a.kv.table_cols : seq64));
+  int chunk = (seq + a.n_splits - 1) / a.n_splits;
+  chunk = (chunk + kTile - 1) / kTile * kTile;
+  const int start = split * chunk;
+  const int end = min(seq, start + chunk);
+  const int32_t* table_row = a.kv.table + req * a.kv.table_row_stride;
+  const uint32_t max_slot = (uint32_t)(a.kv.n_slots - 1);
+  const uint32_t row_units = (uint32_t)(a.kv.slab_row_stride * 2 / 16);
+
+  // ---- Q^T fragments: lane (q = lq, g = lg) holds Q[q][32 s + 8 g .. +8], zero for pad columns
+  uint4 qf[HPT][4];
+  {
+    const char* qrow = (const char*)a.q + (int64_t)row * a.q_row_stride * 2;
+#pragma unroll
+    for (int hh = 0; hh < HPT; ++hh)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        qf[hh][s] = make_uint4(0, 0, 0, 0);
+        if (lq < G) qf[hh][s] = *(const uint4*)(qrow + (((int64_t)(head0 + hh) * G + lq) * D + 32 * s + 8 * lg) * 2);
+      }
+  }
+  const float scale_log2e = a.scale * kLog2e;
+
+  // ---- per-lane DMA source: which piece of a token record this lane moves ----------
+  const int piece = lane % (REC / 16);             // 16-byte piece inside the record
+  const bool piece_is_v = piece >= HPT * 16;
+  const int piece_head = (piece >> 4) % HPT;
+  const int piece_chunk = piece & 15;              // chunk position in LDS
+  const int lane_tok = TOK_PER_DMA == 2 ? (lane >> 5) : 0;  // which token of a DMA instruction
+  // Source address of this lane's piece for slot 0 and record 0.  Slab rows are
+  // 256-byte aligned (host check), so bits 7:4 of a piece address ARE its chunk
+  // index and the record's swizzle is one XOR on the finished address; for two
+  // tokens per instruction the odd token's record adds the lane-constant 4.
+  const uint64_t lane_src = (uint64_t)(piece_is_v ? a.kv.v_slab : a.kv.k_slab) +
+                            (uint64_t)(head0 + piece_head) * (D * 2) + (uint64_t)((piece_chunk ^ (lane_tok << 2)) << 4);
+  // ---- per-lane LDS read offsets -----------------------------------------------------
+  // K rows (A operand): lane (t = lq, g = lg) reads chunk 4 s + g of token t
+  const int k_rec = rec_of_token(lq);
+  int k_off[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) k_off[s] = k_rec * REC + (((4 * s + lg) ^ xr_of_rec(k_rec)) << 4);
+  // V blocks (B operand, transposed read): lane 4 q + p of group g addresses token 4 g + q,
+  // 8-byte piece p of the 32 bytes of d-tile n
+  const int v_rec = rec_of_token(4 * lg + ((lane >> 2) & 3));
+  int v_off[8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n)
+    v_off[n] = v_rec * REC + HPT * 256 + (((2 * n + ((lane >> 1) & 1)) ^ xr_of_rec(v_rec)) << 4) + ((lane & 1) << 3);
+
+  float m_run[HPT], l_run[HPT];
+  f32x4 o_acc[HPT][8];
+#pragma unroll
+  for (int hh = 0; hh < HPT; ++hh) {
+    m_run[hh] = kNegInf;
+    l_run[hh] = 0.f;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) o_acc[hh][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  for (int blk = start; blk < end; blk += kSlotBlock) {
+    const int n_blk = min(kSlotBlock, end - blk);
+    const int n_tiles = (n_blk + kTile - 1) / kTile;
+    for (int i = lane; i < n_blk; i += 64) {
+      const uint32_t s = (uint32_t)table_row[blk + i];
+      // row offset of the slot in 16-byte units (host checked that it fits 32 bits)
+      s_slots[i] = (int32_t)((s > max_slot ? max_slot : s) * row_units);
+    }
+    // (same wave: the LDS writes above are ordered before the LDS reads below)
+    // Retire every load the compiler knows about (q fragments, page-table entries)
+    // HERE, with the builtin it models: inside the tile loop it must find nothing
+    // of its own to wait for, or its vmcnt(0) would also drain the DMA prefetch.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
+
+    auto issue_tile = [&](int tile) {
+      const uint32_t stage = lds_ring + (uint32_t)(tile % NSTAGE) * TILE_BYTES;
+      // lane j holds the row offset of token j of the tile; tokens past the end
+      // re-read the last valid one (finite data, weight 0)
+      const uint32_t tok_off = (uint32_t)s_slots[min(tile * kTile + (lane & 15), n_blk - 1)];
+#pragma unroll
+      for (int i = 0; i < DMA_PER_TILE; ++i) {
+        const int t0 = i * TOK_PER_DMA;  // first token of this instruction
+        uint32_t off = __builtin_amdgcn_readlane(tok_off, t0);
+        if constexpr (TOK_PER_DMA == 2) {
+          const uint32_t off1 = __builtin_amdgcn_readlane(tok_off, t0 + 1);
+          off = lane < 32 ? off : off1;
+        }
+        uint64_t src = ((uint64_t)off << 4) + lane_src;
+        src ^= (uint64_t)(xr_of_rec(rec_of_token(t0)) << 4);
+        dma_1k<NT>((const void*)src, __builtin_amdgcn_readfirstlane(stage + rec_of_token(t0) * REC));
+      }
+    };
+
+#pragma unroll
+    for (int t = 0; t < NSTAGE - 1; ++t)
+      if (t < n_tiles) issue_tile(t);
+
+    for (int tile = 0; tile < n_tiles; ++tile) {
+      const int ahead = n_tiles - 1 - tile;  // tiles issued after this one (capped below)
+      if (ahead >= NSTAGE - 1) {
+        issue_tile(tile + NSTAGE - 1);
+        dma_wait<(NSTAGE - 1) * DMA_PER_TILE>();
+      } else if (NSTAGE > 3 && ahead == 2) {
+        dma_wait<2 * DMA_PER_TILE>();
+      } else if (NSTAGE > 2 && ahead == 1) {
+        dma_wait<1 * DMA_PER_TILE>();
+      } else {
+        dma_wait<0>();
+      }
+      const char* st = smem + (tile % NSTAGE) * TILE_BYTES;
+      const int n_valid = n_blk - tile * kTile;  // >= 1
+
+#pragma unroll
+      for (int hh = 0; hh < HPT; ++hh) {
+        f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const uint4 kf = *(const uint4*)(st + hh * 256 + k_off[s]);
+          sc = Mma<Tag>::qk(kf, qf[hh][s], sc);
+        }
+        // lane (q = lq, g = lg) now holds S^T[token 4 g + r][q], r = 0..3
+        float sv[4];
+        float tmax = kNegInf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          sv[r] = (4 * lg + r < n_valid) ? sc[r] * scale_log2e : kNegInf;
+          tmax = fmaxf(tmax, sv[r]);
+        }
+        tmax = quad_group_max(tmax);
+        if (__any(tmax > m_run[hh])) {
+          const float m_new = fmaxf(m_run[hh], tmax);
+          const float alpha = fast_exp2(m_run[hh] - m_new);  // m_new is finite: the tile has a valid token
+          m_run[hh] = m_new;
+          l_run[hh] *= alpha;
+          // O rows are q = 4 g + r on lane group g: fetch that q's factor
+          float ar[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * lg + r);
+#pragma unroll
+          for (int n = 0; n < 8; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o_acc[hh][n][r] *= ar[r];
+        }
+        float pr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pr[r] = fast_exp2(sv[r] - m_run[hh]);
+          l_run[hh] += pr[r];
+        }
+        // P as the A operand of the 16x16x16 product: lane (q, g) holds P[q][token 4 g + j]
+        const uint2 pf = make_uint2(E::pack2(pr[0], pr[1]), E::pack2(pr[2], pr[3]));
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+          const s16x4_t vf = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(st + hh * 256 + v_off[n]));
+          o_acc[hh][n] = Mma<Tag>::pv(pf, vf, o_acc[hh][n]);
+        }
+      }
+    }
+  }
+
+  // ---- finish: sum l over the lane groups, normalise, write ---------------------------
+  const bool direct = a.n_splits == 1 && a.out_dtype == a.dtype;
+#pragma unroll
+  for (int hh = 0; hh < HPT; ++hh) {
+    const float l = quad_group_sum(l_run[hh]);
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    const float lse = l > 0.f ? (m_run[hh] + __builtin_amdgcn_logf(l)) * kLn2 : kNegInf;
+    float ir[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ir[r] = __shfl(inv, 4 * lg + r);
+    const int hq0 = (head0 + hh) * G;
+    if (lg == 0 && lq < G) {
+      if (direct) {
+        if (a.lse != nullptr) a.lse[(int64_t)row * a.n_q_heads + hq0 + lq] = lse;
+      } else {
+        a.ws_lse[((int64_t)split * a.rows + row) * a.n_q_heads + hq0 + lq] = lse;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = 4 * lg + r;
+      if (q < G) {
+        if (direct) {
+          char* orow = (char*)a.out + ((int64_t)row * a.out_row_stride + (int64_t)(hq0 + q) * D) * 2;
+#pragma unroll
+          for (int n = 0; n < 8; ++n) {
+            const uint32_t packed = E::pack2(o_acc[hh][n][r] * ir[r], 0.f);
+            *(uint16_t*)(orow + (16 * n + lq) * 2) = (uint16_t)packed;
+          }
+        } else {
+          float* po = a.ws_o + (((int64_t)split * a.rows + row) * a.n_q_heads + hq0 + q) * D;
+#pragma unroll
+          for (int n = 0; n < 8; ++n) po[16 * n + lq] = o_acc[hh][n][r] * ir[r];
+        }
+      }
+    }
+  }
+}
+
+int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return (s == nullptr || *s == '\0') ? dflt : atoi(s);
+}
+
+template <typename Tag, int HPT, int NSTAGE>
+hipError_t launch_inst(const DecodeArgs& a, hipStream_t stream) {
+  dim3 grid(a.rows, a.n_kv_heads / HPT, a.n_splits);
+  if (env_int("BSGL_MFMA_NT", 0))
+    hipLaunchKernelGGL((decode_mfma_kernel<Tag, HPT, NSTAGE, true>), grid, dim3(64), 0, stream, a);
+  else
+    hipLaunchKernelGGL((decode_mfma_kernel<Tag, HPT, NSTAGE, false>), grid, dim3(64), 0, stream, a);
+  return hipGetLastError();
+}
+
+template <typename Tag>
+hipError_t launch_tag(const DecodeArgs& a, hipStream_t stream) {
+  // tuning knobs (read per call; defaults are the measured best)
+  const int stages = env_int("BSGL_MFMA_STAGES", 2);
+  const int hpt = (a.n_kv_heads % 2 == 0) ? env_int("BSGL_MFMA_HPT", 2) : 1;
+  if (hpt == 2) {
+    if (stages == 3) return launch_inst<Tag, 2, 3>(a, stream);
+    return launch_inst<Tag, 2, 2>(a, stream);
+  }
+  if (stages == 4) return launch_inst<Tag, 1, 4>(a, stream);
+  if (stages == 3) return launch_inst<Tag, 1, 3>(a, stream);
+  return launch_inst<Tag, 1, 2>(a, stream);
+}
+
+}  // namespace
+
 bool decode_mfma_supported(const DecodeArgs& a, const char** why) {
-  (void)a;
-  *why = "not built yet";
-  return false;
+  if (a.dtype != kBF16 && a.dtype != kF16) {
+    *why = "matrix-core decode needs bf16 or f16";
+    return false;
+  }
+  if (a.head_dim != 128) {
+    *why = "matrix-core decode needs head_dim 128";
+    return false;
+  }
+  if (a.n_kv_heads <= 0 || a.n_q_heads % a.n_kv_heads != 0 || a.n_q_heads / a.n_kv_heads > 16) {
+    *why = "matrix-core decode needs 1..16 query heads per kv head";
+    return false;
+  }
+  const int64_t row_bytes = a.kv.slab_row_stride * 2;
+  if (((uintptr_t)a.kv.k_slab | (uintptr_t)a.kv.v_slab) % 256 != 0 || row_bytes % 256 != 0) {
+    *why = "matrix-core decode needs 256-byte aligned slab rows";
+    return false;
+  }
+  if (a.kv.n_slots * (row_bytes / 16) > 0xffffffffll) {
+    *why = "slab larger than 64 GiB";
+    return false;
+  }
+  return true;
 }
 
 hipError_t launch_decode_mfma(const DecodeArgs& a, hipStream_t stream) {
-  (void)a;
-  (void)stream;
-  return hipErrorNotSupported;
+  if (a.rows == 0) return hipSuccess;
+  hipError_t e = a.dtype == kBF16 ? launch_tag<bf16_tag>(a, stream) : launch_tag<f16_tag>(a, stream);
+  if (e != hipSuccess || decode_direct_out(a)) return e;
+  MergeArgs mg;
+  mg.out = a.out;
+  mg.out_row_stride = a.out_row_stride;
+  mg.lse_out = a.lse;
+  mg.parts_o = a.ws_o;
+  mg.parts_lse = a.ws_lse;
+  mg.n_parts = a.n_splits;
+  mg.rows = a.rows;
+  mg.n_heads = a.n_q_heads;
+  mg.head_dim = a.head_dim;
+  mg.dtype = a.out_dtype;
+  return launch_merge(mg, stream);
 }
 
 }  // namespace bsgl

@@ -100,7 +100,8 @@ __global__ __launch_bounds__(kThreads) void decode_valu_kernel(DecodeArgs a, int
       for (int u = 0; u < U; ++u) {
         const int idx = base + u * tpi + tok_sub;
         valid[u] = idx < n_blk;
-        const int64_t off = (int64_t)(valid[u] ? s_slots[idx] : 0) * row_bytes;
+        // tokens past the end re-read the last valid one (finite data, weight 0)
+        const int64_t off = (int64_t)s_slots[valid[u] ? idx : n_blk - 1] * row_bytes;
         kr[u] = *(const uint4*)(kbase + off);
         vr[u] = *(const uint4*)(vbase + off);
       }
@@ -223,47 +224,56 @@ __global__ __launch_bounds__(kThreads) void decode_valu_kernel(DecodeArgs a, int
   }
 }
 
-// out[row, head, :] = sum_p w_p o_p / sum_p w_p,  w_p = exp(lse_p - max lse)
+// out[row, head, :] = sum_p w_p o_p / sum_p w_p,  w_p = exp(lse_p - max lse).
+// One wave per (row, head): lane p first holds part p's weight (n_parts <= 64),
+// then every lane accumulates its D / 64 output elements over the parts.
 template <typename Tag, int D>
 __global__ __launch_bounds__(256) void merge_states_kernel(MergeArgs a) {
   using E = Elem<Tag>;
-  constexpr int VEC = E::VEC;
-  constexpr int PIECES = D / VEC;
-  constexpr int RPB = 256 / PIECES;
+  constexpr int EPL = D / 64;  // elements per lane
+  const int lane = threadIdx.x & 63;
   const int64_t n_rh = (int64_t)a.rows * a.n_heads;
-  const int64_t rh = (int64_t)blockIdx.x * RPB + threadIdx.x / PIECES;
-  const int piece = threadIdx.x % PIECES;
+  const int64_t rh = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (rh >= n_rh) return;
-  float mx = kNegInf;
-  for (int p = 0; p < a.n_parts; ++p) mx = fmaxf(mx, a.parts_lse[(int64_t)p * n_rh + rh]);
-  float acc[VEC];
+  const float my_lse = lane < a.n_parts ? a.parts_lse[(int64_t)lane * n_rh + rh] : kNegInf;
+  const float mx = group_max<64>(my_lse);
+  const float my_w = (my_lse == kNegInf) ? 0.f : fast_exp2((my_lse - mx) * kLog2e);
+  const float wsum = group_sum<64>(my_w);
+  float acc[EPL];
 #pragma unroll
-  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
-  float wsum = 0.f;
-  if (mx != kNegInf) {
-    for (int p = 0; p < a.n_parts; ++p) {
-      const float lse = a.parts_lse[(int64_t)p * n_rh + rh];
-      const float w = (lse == kNegInf) ? 0.f : fast_exp2((lse - mx) * kLog2e);
-      const float* po = a.parts_o + ((int64_t)p * n_rh + rh) * D + piece * VEC;
-      wsum += w;
+  for (int i = 0; i < EPL; ++i) acc[i] = 0.f;
+  const float* po = a.parts_o + rh * D + lane * EPL;
+  const int64_t part_stride = n_rh * D;
+  for (int p0 = 0; p0 < a.n_parts; p0 += 8) {
+    // 8 parts per round so their loads are in flight together; parts past the end
+    // re-read the last one with weight 0
+    float w[8];
+    float2 v[8];
 #pragma unroll
-      for (int i = 0; i < VEC; i += 4) {
-        const float4 v = *(const float4*)(po + i);
-        acc[i] = fmaf(w, v.x, acc[i]);
-        acc[i + 1] = fmaf(w, v.y, acc[i + 1]);
-        acc[i + 2] = fmaf(w, v.z, acc[i + 2]);
-        acc[i + 3] = fmaf(w, v.w, acc[i + 3]);
-      }
+    for (int j = 0; j < 8; ++j) {
+      const int p = min(p0 + j, a.n_parts - 1);
+      w[j] = p0 + j < a.n_parts ? __shfl(my_w, p) : 0.f;
+      if constexpr (EPL == 2) v[j] = *(const float2*)(po + p * part_stride);
+      else v[j] = make_float2(po[p * part_stride], 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      acc[0] = fmaf(w[j], v[j].x, acc[0]);
+      if constexpr (EPL == 2) acc[1] = fmaf(w[j], v[j].y, acc[1]);
     }
   }
   const float inv = wsum > 0.f ? 1.f / wsum : 0.f;
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) acc[i] *= inv;
   const int64_t row = rh / a.n_heads;
   const int head = (int)(rh % a.n_heads);
-  char* orow = (char*)a.out + row * a.out_row_stride * E::BYTES;
-  *(uint4*)(orow + ((int64_t)head * D + piece * VEC) * E::BYTES) = E::pack(acc);
-  if (a.lse_out != nullptr && piece == 0)
+  char* dst = (char*)a.out + (row * a.out_row_stride + (int64_t)head * D + lane * EPL) * E::BYTES;
+  if constexpr (E::BYTES == 4) {
+    if constexpr (EPL == 2) *(float2*)dst = make_float2(acc[0] * inv, acc[1] * inv);
+    else *(float*)dst = acc[0] * inv;
+  } else {
+    if constexpr (EPL == 2) *(uint32_t*)dst = E::pack2(acc[0] * inv, acc[1] * inv);
+    else *(uint16_t*)dst = (uint16_t)E::pack2(acc[0] * inv, 0.f);
+  }
+  if (a.lse_out != nullptr && lane == 0)
     a.lse_out[rh] = wsum > 0.f ? mx + __builtin_amdgcn_logf(wsum) * kLn2 : kNegInf;
 }
 
@@ -307,13 +317,11 @@ hipError_t launch_valu_d(const DecodeArgs& a, hipStream_t stream) {
 template <typename Tag>
 hipError_t launch_merge_d(const MergeArgs& a, hipStream_t stream) {
   const int64_t n_rh = (int64_t)a.rows * a.n_heads;
-  if (a.head_dim == 128) {
-    constexpr int RPB = 256 / (128 / Elem<Tag>::VEC);
-    hipLaunchKernelGGL((merge_states_kernel<Tag, 128>), dim3((unsigned)((n_rh + RPB - 1) / RPB)), dim3(256), 0, stream, a);
-  } else {
-    constexpr int RPB = 256 / (64 / Elem<Tag>::VEC);
-    hipLaunchKernelGGL((merge_states_kernel<Tag, 64>), dim3((unsigned)((n_rh + RPB - 1) / RPB)), dim3(256), 0, stream, a);
-  }
+  const dim3 grid((unsigned)((n_rh + 3) / 4));
+  if (a.head_dim == 128)
+    hipLaunchKernelGGL((merge_states_kernel<Tag, 128>), grid, dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL((merge_states_kernel<Tag, 64>), grid, dim3(256), 0, stream, a);
   return hipGetLastError();
 }
 

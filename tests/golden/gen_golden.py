@@ -227,7 +227,7 @@ def gen_sched_trace():
 
     torch.manual_seed(0)
     cfg = BabyQwenConfig(
-        vocab_size=97, hidden_size=64, intermediate_size=128, num_hidden_layers=2,
+        vocab_size=97, hidden_size=256, intermediate_size=128, num_hidden_layers=2,
         num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=128,
     )  # fmt: skip
     model = BabyQwen2ForCausalLM(cfg).eval()
@@ -265,7 +265,7 @@ def gen_sched_trace():
     outs = sched.run_batch(prompts, sp)
     ref_backend.SimpleAttentionBackend.forward = staticmethod(fwd)
     record("sched_trace", {
-        "n_q_heads": 4, "n_kv_heads": 2, "head_dim": 16,
+        "n_q_heads": 4, "n_kv_heads": 2, "head_dim": 64,
         "prompts": prompts, "output_ids": [torch.tensor(o) for o in outs], "batches": batches,
     })  # fmt: skip
     print("scheduler batches:", [("P" if b["is_prefill"] else "D", b["seq_lens"].tolist()) for b in batches][:6], "...")
