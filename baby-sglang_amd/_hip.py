@@ -30,6 +30,7 @@ BSGL_ERR_HIP = -3
 BSGL_ERR_WORKSPACE = -4
 
 DECODE_AUTO, DECODE_VALU, DECODE_MFMA = 0, 1, 2
+DECODE_FUSE_KV_WRITE = 0x100  # caller asserts: out_cache_loc slots belong to their own request only
 
 _DTYPE_CODE = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
 
@@ -50,9 +51,11 @@ SIGNATURES = {
     ),
     "bsgl_decode_num_splits": (_i32, [_i32, _i32, _i32]),
     "bsgl_decode_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
+    "bsgl_decode_counter_bytes": (_sz, []),
     "bsgl_paged_decode": (
         ctypes.c_int,
-        [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp]
+        [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _vp]
+        + [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp]
         + [_i32, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _i32, _vp, _sz, _vp],
     ),
     "bsgl_prefill_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
@@ -171,6 +174,12 @@ def decode_workspace_bytes(
     return lib.bsgl_decode_workspace_bytes(batch, n_q_heads, head_dim, n_splits, int(out_is_f32))
 
 
+def new_decode_workspace(n_bytes: int, device) -> torch.Tensor:
+    """Workspace for paged_decode: zero-filled, because its head holds the tickets
+    of the in-kernel split merge, which every call expects (and leaves) at zero."""
+    return torch.zeros(max(int(n_bytes), 16), dtype=torch.uint8, device=device)
+
+
 def paged_decode(
     q: torch.Tensor,
     k_slab: torch.Tensor,
@@ -185,11 +194,20 @@ def paged_decode(
     lse: Optional[torch.Tensor] = None,
     workspace: Optional[torch.Tensor] = None,
     out_dtype: Optional[torch.dtype] = None,
+    k_new: Optional[torch.Tensor] = None,
+    v_new: Optional[torch.Tensor] = None,
+    out_cache_loc: Optional[torch.Tensor] = None,
+    fuse_kv_write: bool = False,
 ) -> torch.Tensor:
     """softmax(q K^T * scale) V over page-table rows; returns [B, Hq * D].
 
     ``out_dtype=torch.float32`` returns unrounded results (with ``lse``, the
-    state a cross-rank merge needs); default is q's dtype.
+    state a cross-rank merge needs); default is q's dtype.  ``k_new`` /
+    ``v_new`` / ``out_cache_loc`` (together) are stored into the slabs before
+    attention reads them; ``fuse_kv_write`` lets the library do that inside the
+    decode kernel, which is only valid when each slot in ``out_cache_loc`` is
+    referenced by its own request's page-table row alone.  A caller-provided
+    ``workspace`` must have been created zero-filled (``new_decode_workspace``).
     """
     _need_gpu(q, k_slab, v_slab, req_to_token, req_pool_indices, seq_lens)
     q = _rows(q)
@@ -217,10 +235,27 @@ def paged_decode(
         n_splits = decode_num_splits(batch, hkv, req_to_token.shape[1])
     need = decode_workspace_bytes(batch, hq, dim, n_splits, out_dtype != q.dtype)
     if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
-        workspace = torch.empty(need, dtype=torch.uint8, device=q.device)
+        workspace = torch.zeros(need, dtype=torch.uint8, device=q.device)
+    new = (None, None, 0, 0, None)
+    if k_new is not None or v_new is not None or out_cache_loc is not None:
+        if k_new is None or v_new is None or out_cache_loc is None:
+            raise ValueError("k_new, v_new and out_cache_loc go together")
+        k_new = _rows(k_new.view(batch, hkv, dim) if k_new.dim() == 2 else k_new)
+        v_new = _rows(v_new.view(batch, hkv, dim) if v_new.dim() == 2 else v_new)
+        if k_new.dtype != q.dtype or v_new.dtype != q.dtype:
+            raise ValueError("new K/V rows must have q's dtype")
+        if tuple(k_new.shape) != (batch, hkv, dim) or tuple(v_new.shape) != (batch, hkv, dim):
+            raise ValueError("new K/V rows must be [batch, n_kv_heads, head_dim]")
+        loc = out_cache_loc if out_cache_loc.dtype == torch.int32 else out_cache_loc.to(torch.int32)
+        loc = loc if loc.is_contiguous() else loc.contiguous()
+        if loc.shape[0] != batch:
+            raise ValueError("out_cache_loc must have one slot per request")
+        new = (k_new.data_ptr(), v_new.data_ptr(), k_new.stride(0), v_new.stride(0), loc.data_ptr())
+        if fuse_kv_write:
+            variant |= DECODE_FUSE_KV_WRITE
     rc = lib.bsgl_paged_decode(
         out.data_ptr(), out.stride(0), lse.data_ptr() if lse is not None else None,
-        q.data_ptr(), q.stride(0),
+        q.data_ptr(), q.stride(0), *new,
         k_slab.data_ptr(), v_slab.data_ptr(), k_slab.stride(0), k_slab.shape[0],
         req_to_token.data_ptr(), req_to_token.stride(0), req_to_token.shape[0], req_to_token.shape[1],
         req_pool_indices.data_ptr(), seq_lens.data_ptr(),

@@ -33,6 +33,16 @@ class SimpleAttentionBackend:
     # decode kernel selection: _hip.DECODE_AUTO picks the matrix-core kernel
     # when it covers the shape, the generic kernel otherwise
     decode_variant = _hip.DECODE_AUTO
+    # Decode steps hand the new token's K/V rows to the decode kernel, which
+    # stores them itself instead of a separate scatter launch.  Valid because
+    # the scheduler gives every decode token a fresh slot that only its own
+    # request's page-table row names (scheduler.py:459-490); set to False to
+    # keep the write a launch of its own.
+    fuse_decode_kv_write = True
+    # one zero-initialised decode workspace per (device, stream): calls on
+    # different streams may overlap (overlap_worker.py:104-127) and must not
+    # share split-merge tickets
+    _workspaces = {}
 
     @staticmethod
     def forward(
@@ -45,25 +55,54 @@ class SimpleAttentionBackend:
     ) -> torch.Tensor:
         layer_id = attention_layer.layer_id
         pool = forward_batch.token_to_kv_pool
-
-        if save_kv_cache and k is not None and v is not None:
-            pool.set_kv_buffer(layer_id, forward_batch.out_cache_loc, k, v)
+        write_kv = save_kv_cache and k is not None and v is not None
 
         if forward_batch.is_prefill:
+            if write_kv:
+                pool.set_kv_buffer(layer_id, forward_batch.out_cache_loc, k, v)
             return SimpleAttentionBackend._prefill_attention(q, forward_batch, layer_id)
-        return SimpleAttentionBackend._decode_attention(q, forward_batch, layer_id)
+        if write_kv and k.dtype != pool.dtype:
+            # the pool casts on write (memory_pool.py:163-165); keep that path separate
+            pool.set_kv_buffer(layer_id, forward_batch.out_cache_loc, k, v)
+            write_kv = False
+        return SimpleAttentionBackend._decode_attention(
+            q, k if write_kv else None, v if write_kv else None, forward_batch, layer_id
+        )
 
     @staticmethod
-    def _decode_attention(q, forward_batch: SimplifiedForwardBatch, layer_id: int):
-        k_slab, v_slab = forward_batch.token_to_kv_pool.get_kv_buffer(layer_id)
+    def _decode_workspace(q, n_q_heads: int, n_kv_heads: int, max_ctx: int):
+        batch, dim = q.shape[0], q.shape[-1]
+        n_splits = _hip.decode_num_splits(batch, n_kv_heads, max_ctx)
+        need = _hip.decode_workspace_bytes(batch, n_q_heads, dim, n_splits)
+        key = (q.device, torch.cuda.current_stream(q.device).cuda_stream)
+        ws = SimpleAttentionBackend._workspaces.get(key)
+        if ws is None or ws.numel() < need:
+            ws = _hip.new_decode_workspace(max(need, 1 << 20), q.device)
+            SimpleAttentionBackend._workspaces[key] = ws
+        return n_splits, ws
+
+    @staticmethod
+    def _decode_attention(q, k, v, forward_batch: SimplifiedForwardBatch, layer_id: int):
+        pool = forward_batch.token_to_kv_pool
+        if pool.store_dtype != pool.dtype:
+            raise NotImplementedError("float8 KV cache write is not supported in baby-sglang MVP")
+        k_slab, v_slab = pool.get_kv_buffer(layer_id)
+        table = forward_batch.req_to_token_pool.req_to_token
+        n_splits, ws = SimpleAttentionBackend._decode_workspace(q, q.shape[1], k_slab.shape[1], table.shape[1])
         return _hip.paged_decode(
             q,
             k_slab,
             v_slab,
-            forward_batch.req_to_token_pool.req_to_token,
+            table,
             forward_batch.req_pool_indices,
             forward_batch.seq_lens,
+            n_splits=n_splits,
             variant=SimpleAttentionBackend.decode_variant,
+            workspace=ws,
+            k_new=k,
+            v_new=v,
+            out_cache_loc=forward_batch.out_cache_loc if k is not None else None,
+            fuse_kv_write=SimpleAttentionBackend.fuse_decode_kv_write,
         )
 
     @staticmethod

@@ -45,6 +45,13 @@ struct DecodeArgs {
   int32_t n_splits;
   float* ws_o;    // [n_splits, rows * n_q_heads, head_dim]   (unless direct)
   float* ws_lse;  // [n_splits, rows * n_q_heads]
+  uint32_t* counters;  // [rows, head groups] tickets of the in-kernel merge; zero between launches; may be NULL
+  // fused KV write of the new token of each row (decode only); new_loc == NULL disables it
+  const void* k_new;
+  const void* v_new;
+  int64_t k_new_stride;
+  int64_t v_new_stride;
+  const int32_t* new_loc;
 };
 
 struct MergeArgs {

@@ -69,9 +69,15 @@ int check_paged(const void* out, int64_t out_row_stride, const void* q, int64_t 
   return BSGL_OK;
 }
 
-int run_decode(const bsgl::DecodeArgs& a, int32_t variant, hipStream_t stream) {
+// fixed-size ticket area at the head of every decode workspace, so that its place
+// does not move when one workspace serves calls of different batch sizes
+constexpr size_t kCounterBytes = 65536;
+
+int run_decode(bsgl::DecodeArgs& a, int32_t variant, uint32_t* counters, hipStream_t stream) {
   const char* why = "";
   bool use_mfma = false;
+  const bool may_fuse_kv = (variant & BSGL_DECODE_FUSE_KV_WRITE) != 0;
+  variant &= 0xff;
   if (variant == BSGL_DECODE_MFMA) {
     if (!bsgl::decode_mfma_supported(a, &why)) return fail(BSGL_ERR_UNSUPPORTED, "MFMA decode: %s", why);
     use_mfma = true;
@@ -81,6 +87,35 @@ int run_decode(const bsgl::DecodeArgs& a, int32_t variant, hipStream_t stream) {
     return fail(BSGL_ERR_BAD_ARG, "unknown decode variant %d", variant);
   }
   if (!use_mfma && !bsgl::decode_valu_supported(a, &why)) return fail(BSGL_ERR_UNSUPPORTED, "decode: %s", why);
+  // KV write of the new tokens: inside the matrix-core kernel when the caller
+  // allows it and the rows qualify, otherwise as its own launch first
+  if (a.new_loc != nullptr) {
+    const int eb = bsgl::dtype_bytes(a.dtype);
+    const bool rows_ok = (((uintptr_t)a.k_new | (uintptr_t)a.v_new) % 256 == 0) &&
+                         (a.k_new_stride * eb) % 256 == 0 && (a.v_new_stride * eb) % 256 == 0;
+    if (!(use_mfma && may_fuse_kv && rows_ok && env_int("BSGL_NO_FUSED_KV", 0) == 0)) {
+      bsgl::ScatterArgs sc;
+      sc.k_slab = const_cast<void*>(a.kv.k_slab);
+      sc.v_slab = const_cast<void*>(a.kv.v_slab);
+      sc.slab_row_stride = a.kv.slab_row_stride;
+      sc.n_slots = a.kv.n_slots;
+      sc.loc = a.new_loc;
+      sc.k_new = a.k_new;
+      sc.v_new = a.v_new;
+      sc.k_row_stride = a.k_new_stride;
+      sc.v_row_stride = a.v_new_stride;
+      sc.n_tok = a.rows;
+      sc.row_bytes = a.n_kv_heads * a.head_dim * eb;
+      sc.elem_bytes = eb;
+      const hipError_t es = bsgl::launch_kv_scatter(sc, stream);
+      if (es != hipSuccess) return hip_fail("kv_scatter launch", es);
+      a.new_loc = nullptr;
+    }
+  }
+  // one ticket per (row, kv head): fall back to the merge kernel when they do not fit
+  const bool tickets_fit = (size_t)a.rows * (size_t)a.n_kv_heads * 4 <= kCounterBytes &&
+                           (size_t)a.n_splits * a.rows * a.n_q_heads * a.head_dim * 4 < (1ull << 31);
+  a.counters = (use_mfma && tickets_fit && env_int("BSGL_NO_FUSED_MERGE", 0) == 0) ? counters : nullptr;
   const hipError_t e = use_mfma ? bsgl::launch_decode_mfma(a, stream) : bsgl::launch_decode_valu(a, stream);
   if (e != hipSuccess) return hip_fail("decode launch", e);
   return BSGL_OK;
@@ -133,13 +168,15 @@ int bsgl_kv_scatter(void* k_slab, void* v_slab, int64_t slab_row_stride, int64_t
 }
 
 int32_t bsgl_decode_num_splits(int32_t batch, int32_t n_kv_heads, int32_t max_context_len) {
-  (void)n_kv_heads;
   if (batch <= 0) return 1;
+  if (n_kv_heads < 1) n_kv_heads = 1;
   // enough workgroups to put several on each of the 256 CUs, but no split
   // shorter than min_chunk tokens of the longest possible request
   const int target_wgs = env_int("BSGL_DECODE_TARGET_WGS", 1024);
   const int min_chunk = env_int("BSGL_DECODE_MIN_CHUNK", 128);
-  int splits = (target_wgs + batch - 1) / batch;
+  // one workgroup per (request, kv head, split)
+  const int64_t per_split = (int64_t)batch * n_kv_heads;
+  int splits = (int)((target_wgs + per_split - 1) / per_split);
   const int by_len = max_context_len > 0 ? (max_context_len + min_chunk - 1) / min_chunk : 1;
   if (splits > by_len) splits = by_len;
   if (splits > 64) splits = 64;
@@ -147,15 +184,20 @@ int32_t bsgl_decode_num_splits(int32_t batch, int32_t n_kv_heads, int32_t max_co
   return splits;
 }
 
+size_t bsgl_decode_counter_bytes(void) { return kCounterBytes; }
+
 size_t bsgl_decode_workspace_bytes(int32_t batch, int32_t n_q_heads, int32_t head_dim, int32_t n_splits,
                                    int32_t out_is_f32) {
   if (batch <= 0 || n_splits < 1 || (n_splits == 1 && !out_is_f32)) return 0;
   const size_t rh = (size_t)batch * (size_t)n_q_heads;
-  return align_up((size_t)n_splits * rh * (size_t)head_dim * 4, 256) + align_up((size_t)n_splits * rh * 4, 256);
+  return kCounterBytes + align_up((size_t)n_splits * rh * (size_t)head_dim * 4, 256) +
+         align_up((size_t)n_splits * rh * 4, 256);
 }
 
 int bsgl_paged_decode(void* out, int64_t out_row_stride, float* lse, const void* q, int64_t q_row_stride,
-                      const void* k_slab, const void* v_slab, int64_t slab_row_stride, int64_t n_slots,
+                      const void* k_new, const void* v_new, int64_t k_new_row_stride, int64_t v_new_row_stride,
+                      const int32_t* out_cache_loc,
+                      void* k_slab, void* v_slab, int64_t slab_row_stride, int64_t n_slots,
                       const int32_t* req_to_token, int64_t table_row_stride, int64_t table_rows,
                       int64_t table_cols, const int64_t* req_pool_indices, const int64_t* seq_lens,
                       int32_t batch, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim, float scale,
@@ -165,10 +207,25 @@ int bsgl_paged_decode(void* out, int64_t out_row_stride, float* lse, const void*
   if (out_dtype != dtype && out_dtype != BSGL_DTYPE_F32)
     return fail(BSGL_ERR_BAD_ARG, "out_dtype must equal dtype or be f32");
   if (batch == 0) return BSGL_OK;
-  bsgl::DecodeArgs a;
+  bsgl::DecodeArgs a{};
   a.kv = {k_slab, v_slab, slab_row_stride, n_slots, req_to_token, table_row_stride, table_rows, table_cols};
   if (int rc = check_paged(out, out_row_stride, q, q_row_stride, a.kv, n_q_heads, n_kv_heads, head_dim, dtype)) return rc;
   if (!req_pool_indices || !seq_lens) return fail(BSGL_ERR_BAD_ARG, "null req_pool_indices / seq_lens");
+  const int n_new = (k_new != nullptr) + (v_new != nullptr) + (out_cache_loc != nullptr);
+  if (n_new != 0 && n_new != 3) return fail(BSGL_ERR_BAD_ARG, "k_new, v_new and out_cache_loc must be given together");
+  if (n_new == 3) {
+    const int64_t eb = bsgl::dtype_bytes(dtype);
+    const int64_t row_bytes = (int64_t)n_kv_heads * head_dim * eb;
+    if (!aligned16(k_new) || !aligned16(v_new) || (k_new_row_stride * eb) % 16 || (v_new_row_stride * eb) % 16)
+      return fail(BSGL_ERR_BAD_ARG, "new K/V rows must be 16-byte aligned with 16-byte-multiple strides");
+    if (k_new_row_stride * eb < row_bytes || v_new_row_stride * eb < row_bytes)
+      return fail(BSGL_ERR_BAD_ARG, "new K/V row stride shorter than the KV row");
+    a.k_new = k_new;
+    a.v_new = v_new;
+    a.k_new_stride = k_new_row_stride;
+    a.v_new_stride = v_new_row_stride;
+    a.new_loc = out_cache_loc;
+  }
   if (n_splits < 1 || n_splits > 64) return fail(BSGL_ERR_BAD_ARG, "n_splits %d outside [1, 64]", n_splits);
   const int f32_out = out_dtype != dtype;
   if (f32_out && (((uintptr_t)out & 15u) || (out_row_stride * 4) % 16))
@@ -192,14 +249,16 @@ int bsgl_paged_decode(void* out, int64_t out_row_stride, float* lse, const void*
   a.out_dtype = out_dtype;
   a.n_splits = n_splits;
   const size_t rh = (size_t)batch * (size_t)n_q_heads;
-  a.ws_o = (float*)workspace;
-  a.ws_lse = need ? (float*)((char*)workspace + align_up((size_t)n_splits * rh * (size_t)head_dim * 4, 256)) : nullptr;
-  return run_decode(a, variant, (hipStream_t)stream);
+  const size_t cb = kCounterBytes;
+  a.ws_o = need ? (float*)((char*)workspace + cb) : nullptr;
+  a.ws_lse = need ? (float*)((char*)workspace + cb + align_up((size_t)n_splits * rh * (size_t)head_dim * 4, 256)) : nullptr;
+  return run_decode(a, variant, need ? (uint32_t*)workspace : nullptr, (hipStream_t)stream);
 }
 
 static int32_t prefill_row_splits(int32_t total_q_tokens, int32_t max_context_len) {
   return bsgl_decode_num_splits(total_q_tokens, 1, max_context_len);
 }
+
 
 size_t bsgl_prefill_workspace_bytes(int32_t batch, int32_t total_q_tokens, int32_t n_q_heads, int32_t head_dim) {
   if (batch <= 0 || total_q_tokens <= 0) return 0;
@@ -221,7 +280,7 @@ int bsgl_paged_prefill(void* out, int64_t out_row_stride, const void* q, int64_t
                        size_t workspace_bytes, void* stream) {
   if (batch < 0 || total_q_tokens < 0) return fail(BSGL_ERR_BAD_ARG, "batch / total_q_tokens < 0");
   if (batch == 0 || total_q_tokens == 0) return BSGL_OK;
-  bsgl::DecodeArgs a;
+  bsgl::DecodeArgs a{};
   a.kv = {k_slab, v_slab, slab_row_stride, n_slots, req_to_token, table_row_stride, table_rows, table_cols};
   if (int rc = check_paged(out, out_row_stride, q, q_row_stride, a.kv, n_q_heads, n_kv_heads, head_dim, dtype)) return rc;
   if (!req_pool_indices || !seq_lens || !prefix_lens || !extended_lens)
@@ -265,10 +324,11 @@ int bsgl_paged_prefill(void* out, int64_t out_row_stride, const void* q, int64_t
   a.out_dtype = dtype;
   a.n_splits = splits;
   const size_t rh = (size_t)total_q_tokens * (size_t)n_q_heads;
-  a.ws_o = (float*)ws;
-  a.ws_lse = splits > 1 ? (float*)(ws + align_up((size_t)splits * rh * (size_t)head_dim * 4, 256)) : nullptr;
+  const size_t cb = kCounterBytes;
+  a.ws_o = (float*)(ws + cb);
+  a.ws_lse = splits > 1 ? (float*)(ws + cb + align_up((size_t)splits * rh * (size_t)head_dim * 4, 256)) : nullptr;
   (void)variant;
-  return run_decode(a, BSGL_DECODE_VALU, (hipStream_t)stream);
+  return run_decode(a, BSGL_DECODE_VALU, nullptr, (hipStream_t)stream);
 }
 
 int bsgl_merge_attn_states(void* out, int64_t out_row_stride, float* lse_out, const float* parts_o,

@@ -25,6 +25,19 @@
 // transposed V reads are bank-conflict free and the K row reads 2-way.  The DMA
 // destination is linear in the lane, so the swizzle is applied to each lane's
 // SOURCE address.
+//
+// Fused KV write (optional): when the new token's K/V rows are handed in, the
+// split-0 workgroup copies them into the slab, and every DMA whose page-table
+// slot equals the row's new slot reads the NEW rows instead of the slab, so the
+// write needs no earlier kernel and no ordering against the gather.
+//
+// Fused merge (when the sequence is split): a workgroup stores its normalised
+// partial output and log-sum-exp write-through (sc1, 16 bytes per lane via an
+// LDS transpose), drains its stores, then draws a ticket with one agent-scope
+// atomic add on the (row, head group) counter.  The workgroup that draws the
+// last ticket reads every partial back with sc1 loads (they bypass its L1),
+// merges them and writes the final rows, then stores 0 to the counter: counters
+// are zero before and after every launch.
 #include "bsgl_device.h"
 #include "bsgl_launch.h"
 
@@ -33,6 +46,8 @@ namespace bsgl {
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
@@ -189,8 +204,29 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(DecodeArgs a) {
   // 256-byte aligned (host check), so bits 7:4 of a piece address ARE its chunk
   // index and the record's swizzle is one XOR on the finished address; for two
   // tokens per instruction the odd token's record adds the lane-constant 4.
-  const uint64_t lane_src = (uint64_t)(piece_is_v ? a.kv.v_slab : a.kv.k_slab) +
-                            (uint64_t)(head0 + piece_head) * (D * 2) + (uint64_t)((piece_chunk ^ (lane_tok << 2)) << 4);
+  const uint64_t piece_off = (uint64_t)(head0 + piece_head) * (D * 2) + (uint64_t)((piece_chunk ^ (lane_tok << 2)) << 4);
+  const uint64_t lane_src = (uint64_t)(piece_is_v ? a.kv.v_slab : a.kv.k_slab) + piece_off;
+
+  // ---- fused KV write: this row's new token ------------------------------------------
+  constexpr uint32_t kNewTok = 0xffffffffu;        // row-offset value that marks "read the new rows"
+  const bool fuse_kv = a.new_loc != nullptr;
+  uint32_t new_slot = kNewTok;
+  uint64_t lane_new_src = 0;
+  if (fuse_kv) {
+    const int32_t loc = a.new_loc[row];
+    if (loc >= 0 && (uint32_t)loc <= max_slot) new_slot = (uint32_t)loc;
+    const uint64_t new_row = piece_is_v ? (uint64_t)a.v_new + (uint64_t)row * a.v_new_stride * 2
+                                        : (uint64_t)a.k_new + (uint64_t)row * a.k_new_stride * 2;
+    lane_new_src = new_row + piece_off;
+    if (split == 0 && new_slot != kNewTok && lane < REC / 16) {
+      // copy this head group's new K and V rows into the slab (plain chunk order)
+      const uint64_t o = (uint64_t)(head0 + piece_head) * (D * 2) + (uint64_t)(piece_chunk << 4);
+      const uint4 val = *(const uint4*)(new_row + o);
+      char* slab = piece_is_v ? (char*)a.kv.v_slab : (char*)a.kv.k_slab;
+      *(uint4*)(slab + (uint64_t)new_slot * row_units * 16 + o) = val;
+    }
+  }
+
   // ---- per-lane LDS read offsets -----------------------------------------------------
   // K rows (A operand): lane (t = lq, g = lg) reads chunk 4 s + g of token t
   const int k_rec = rec_of_token(lq);
@@ -219,9 +255,10 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(DecodeArgs a) {
     const int n_blk = min(kSlotBlock, end - blk);
     const int n_tiles = (n_blk + kTile - 1) / kTile;
     for (int i = lane; i < n_blk; i += 64) {
-      const uint32_t s = (uint32_t)table_row[blk + i];
-      // row offset of the slot in 16-byte units (host checked that it fits 32 bits)
-      s_slots[i] = (int32_t)((s > max_slot ? max_slot : s) * row_units);
+      uint32_t s = (uint32_t)table_row[blk + i];
+      s = s > max_slot ? max_slot : s;
+      // row offset of the slot in 16-byte units (host checked that it stays below 2^32 - 1)
+      s_slots[i] = (int32_t)(s == new_slot ? kNewTok : s * row_units);
     }
     // (same wave: the LDS writes above are ordered before the LDS reads below)
     // Retire every load the compiler knows about (q fragments, page-table entries)
@@ -242,7 +279,7 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(DecodeArgs a) {
           const uint32_t off1 = __builtin_amdgcn_readlane(tok_off, t0 + 1);
           off = lane < 32 ? off : off1;
         }
-        uint64_t src = ((uint64_t)off << 4) + lane_src;
+        uint64_t src = off == kNewTok ? lane_new_src : ((uint64_t)off << 4) + lane_src;
         src ^= (uint64_t)(xr_of_rec(rec_of_token(t0)) << 4);
         dma_1k<NT>((const void*)src, __builtin_amdgcn_readfirstlane(stage + rec_of_token(t0) * REC));
       }
@@ -318,6 +355,12 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(DecodeArgs a) {
 
   // ---- finish: sum l over the lane groups, normalise, write ---------------------------
   const bool direct = a.n_splits == 1 && a.out_dtype == a.dtype;
+  const bool fused_merge = !direct && a.counters != nullptr;
+  const int64_t n_rh = (int64_t)a.rows * a.n_q_heads;
+  float* o_lds = (float*)smem;          // the ring is idle now: [16 q][kOPad] floats per head
+  constexpr int kOPad = D + 4;
+  const auto ws_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ws_o + ((int64_t)split * n_rh + (int64_t)row * a.n_q_heads) * D), 0,
+                                                         (int)(a.n_q_heads * D * 4), 0x00020000);
 #pragma unroll
   for (int hh = 0; hh < HPT; ++hh) {
     const float l = quad_group_sum(l_run[hh]);
@@ -327,32 +370,115 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(DecodeArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) ir[r] = __shfl(inv, 4 * lg + r);
     const int hq0 = (head0 + hh) * G;
-    if (lg == 0 && lq < G) {
-      if (direct) {
-        if (a.lse != nullptr) a.lse[(int64_t)row * a.n_q_heads + hq0 + lq] = lse;
-      } else {
-        a.ws_lse[((int64_t)split * a.rows + row) * a.n_q_heads + hq0 + lq] = lse;
-      }
-    }
+    if (direct) {
+      if (lg == 0 && lq < G && a.lse != nullptr) a.lse[(int64_t)row * a.n_q_heads + hq0 + lq] = lse;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int q = 4 * lg + r;
-      if (q < G) {
-        if (direct) {
+      for (int r = 0; r < 4; ++r) {
+        const int q = 4 * lg + r;
+        if (q < G) {
           char* orow = (char*)a.out + ((int64_t)row * a.out_row_stride + (int64_t)(hq0 + q) * D) * 2;
 #pragma unroll
-          for (int n = 0; n < 8; ++n) {
-            const uint32_t packed = E::pack2(o_acc[hh][n][r] * ir[r], 0.f);
-            *(uint16_t*)(orow + (16 * n + lq) * 2) = (uint16_t)packed;
-          }
-        } else {
-          float* po = a.ws_o + (((int64_t)split * a.rows + row) * a.n_q_heads + hq0 + q) * D;
+          for (int n = 0; n < 8; ++n) *(uint16_t*)(orow + (16 * n + lq) * 2) = (uint16_t)E::pack2(o_acc[hh][n][r] * ir[r], 0.f);
+        }
+      }
+      continue;
+    }
+    // partial state: rows through LDS so that every lane stores 16 contiguous bytes
+    if (lg == 0 && lq < G) {
+      float* pl = a.ws_lse + (int64_t)split * n_rh + (int64_t)row * a.n_q_heads + hq0 + lq;
+      if (fused_merge) __hip_atomic_store(pl, lse, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else *pl = lse;
+    }
 #pragma unroll
-          for (int n = 0; n < 8; ++n) po[16 * n + lq] = o_acc[hh][n][r] * ir[r];
+    for (int n = 0; n < 8; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o_lds[(4 * lg + r) * kOPad + 16 * n + lq] = o_acc[hh][n][r] * ir[r];
+    for (int idx = lane; idx < G * (D / 4); idx += 64) {
+      const int q = idx / (D / 4), c4 = idx % (D / 4);
+      const f32x4 v = *(const f32x4*)(o_lds + q * kOPad + c4 * 4);
+      // aux 16 = sc1: write-through, so the merging workgroup's sc1 loads see the bytes
+      const int off = ((hq0 + q) * D + c4 * 4) * 4;
+      if (fused_merge) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ws_rsrc, off, 0, 16);
+      else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ws_rsrc, off, 0, 0);
+    }
+  }
+  if (!fused_merge) return;
+
+  // ---- ticket: the last workgroup of this (row, head group) merges all splits ----------
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every partial byte of this wave has left
+  uint32_t* counter = a.counters + (int64_t)row * gridDim.y + blockIdx.y;
+  uint32_t ticket = 0;
+  if (lane == 0) ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ticket = __builtin_amdgcn_readfirstlane(ticket);
+  if (ticket != (uint32_t)a.n_splits - 1) return;
+
+  // All partial bytes were stored sc1 and drained before their tickets; read them
+  // back with sc1 loads only (aux 16), which bypass this CU's vector cache.
+  // Lane p owns part p's weight (n_splits <= 64); loads of up to 8 heads x 8 parts
+  // are issued together so the merge costs two memory round trips, not one per head.
+  const int n_parts = a.n_splits;
+  const int nh = HPT * G;
+  const int64_t rh0 = (int64_t)row * a.n_q_heads + (int64_t)head0 * G;
+  const auto lse_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ws_lse + rh0), 0, (int)(((int64_t)(n_parts - 1) * n_rh + nh) * 4), 0x00020000);
+  const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ws_o + rh0 * D), 0, (int)((((int64_t)(n_parts - 1) * n_rh + nh) * D) * 4), 0x00020000);
+  const int part_lse_stride = (int)(n_rh * 4);
+  const int part_o_stride = (int)(n_rh * D * 4);
+  for (int h0 = 0; h0 < nh; h0 += 8) {
+    float my_lse[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int h = min(h0 + j, nh - 1);
+      my_lse[j] = lane < n_parts
+          ? as_f32(__builtin_amdgcn_raw_buffer_load_b32(lse_rsrc, lane * part_lse_stride + h * 4, 0, 16)) : kNegInf;
+    }
+    float acc[8][2];
+    float my_w[8], mx[8], wsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j][0] = acc[j][1] = 0.f;
+    for (int p0 = 0; p0 < n_parts; p0 += 8) {
+      u32x2_t v[8][8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int h = min(h0 + j, nh - 1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int p = min(p0 + i, n_parts - 1);
+          v[j][i] = __builtin_amdgcn_raw_buffer_load_b64(o_rsrc, p * part_o_stride + (h * D + lane * 2) * 4, 0, 16);
+        }
+      }
+      if (p0 == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          mx[j] = group_max<64>(my_lse[j]);
+          my_w[j] = (my_lse[j] == kNegInf) ? 0.f : fast_exp2((my_lse[j] - mx[j]) * kLog2e);
+          wsum[j] = group_sum<64>(my_w[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float w = p0 + i < n_parts ? __shfl(my_w[j], min(p0 + i, n_parts - 1)) : 0.f;
+          acc[j][0] = fmaf(w, as_f32(v[j][i].x), acc[j][0]);
+          acc[j][1] = fmaf(w, as_f32(v[j][i].y), acc[j][1]);
         }
       }
     }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (h0 + j >= nh) break;
+      const float inv = wsum[j] > 0.f ? 1.f / wsum[j] : 0.f;
+      const int64_t hq = (int64_t)head0 * G + h0 + j;
+      if (a.out_dtype == kF32) {
+        *(float2*)((char*)a.out + ((int64_t)row * a.out_row_stride + hq * D + lane * 2) * 4) = make_float2(acc[j][0] * inv, acc[j][1] * inv);
+      } else {
+        *(uint32_t*)((char*)a.out + ((int64_t)row * a.out_row_stride + hq * D + lane * 2) * 2) = E::pack2(acc[j][0] * inv, acc[j][1] * inv);
+      }
+      if (a.lse != nullptr && lane == 0)
+        a.lse[rh0 + h0 + j] = wsum[j] > 0.f ? mx[j] + __builtin_amdgcn_logf(wsum[j]) * kLn2 : kNegInf;
+    }
   }
+  if (lane == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 int env_int(const char* name, int dflt) {
@@ -363,7 +489,7 @@ int env_int(const char* name, int dflt) {
 template <typename Tag, int HPT, int NSTAGE>
 hipError_t launch_inst(const DecodeArgs& a, hipStream_t stream) {
   dim3 grid(a.rows, a.n_kv_heads / HPT, a.n_splits);
-  if (env_int("BSGL_MFMA_NT", 0))
+  if (env_int("BSGL_MFMA_NT", 1))
     hipLaunchKernelGGL((decode_mfma_kernel<Tag, HPT, NSTAGE, true>), grid, dim3(64), 0, stream, a);
   else
     hipLaunchKernelGGL((decode_mfma_kernel<Tag, HPT, NSTAGE, false>), grid, dim3(64), 0, stream, a);
@@ -374,7 +500,7 @@ template <typename Tag>
 hipError_t launch_tag(const DecodeArgs& a, hipStream_t stream) {
   // tuning knobs (read per call; defaults are the measured best)
   const int stages = env_int("BSGL_MFMA_STAGES", 2);
-  const int hpt = (a.n_kv_heads % 2 == 0) ? env_int("BSGL_MFMA_HPT", 2) : 1;
+  const int hpt = (a.n_kv_heads % 2 == 0) ? env_int("BSGL_MFMA_HPT", 1) : 1;
   if (hpt == 2) {
     if (stages == 3) return launch_inst<Tag, 2, 3>(a, stream);
     return launch_inst<Tag, 2, 2>(a, stream);
@@ -404,7 +530,7 @@ bool decode_mfma_supported(const DecodeArgs& a, const char** why) {
     *why = "matrix-core decode needs 256-byte aligned slab rows";
     return false;
   }
-  if (a.kv.n_slots * (row_bytes / 16) > 0xffffffffll) {
+  if (a.kv.n_slots * (row_bytes / 16) >= 0xffffffffll) {
     *why = "slab larger than 64 GiB";
     return false;
   }
@@ -414,7 +540,7 @@ bool decode_mfma_supported(const DecodeArgs& a, const char** why) {
 hipError_t launch_decode_mfma(const DecodeArgs& a, hipStream_t stream) {
   if (a.rows == 0) return hipSuccess;
   hipError_t e = a.dtype == kBF16 ? launch_tag<bf16_tag>(a, stream) : launch_tag<f16_tag>(a, stream);
-  if (e != hipSuccess || decode_direct_out(a)) return e;
+  if (e != hipSuccess || decode_direct_out(a) || a.counters != nullptr) return e;
   MergeArgs mg;
   mg.out = a.out;
   mg.out_row_stride = a.out_row_stride;

@@ -53,6 +53,7 @@ def parse_args():
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
                     help="replay the 28-layer step from a HIP graph, or launch it from Python each step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-fuse", action="store_true", help="KV write as its own launch instead of inside the decode kernel")
     ap.add_argument("--no-extras", action="store_true", help="skip the contiguous-table and eager/graph side measurements")
     return ap.parse_args()
 
@@ -100,7 +101,7 @@ class Workload:
         self.n_splits = args.splits or pkg._hip.decode_num_splits(B, self.hkv_l, args.max_context)
         self.out_f32 = layout.tp_seq > 1
         ws = pkg._hip.decode_workspace_bytes(B, self.hq_l, self.dim, self.n_splits, self.out_f32)
-        self.workspace = torch.empty(max(ws, 16), dtype=torch.uint8, device=dev)
+        self.workspace = pkg._hip.new_decode_workspace(ws, dev)
         self.lse = torch.empty((B, self.hq_l), dtype=torch.float32, device=dev) if self.out_f32 else None
         self.out = torch.empty((B, self.hq_l * self.dim), dtype=torch.float32 if self.out_f32 else self.dtype, device=dev)
         self.full_out = None
@@ -121,13 +122,15 @@ class Workload:
     def attention_layer(self, layer, tp_group=None):
         """KV write + paged decode (+ the TP exchange) of one layer."""
         hip = self.pkg._hip
-        if self.writes_kv:
-            self.kv.set_kv_buffer(layer, self.loc, self.k[layer], self.v_rows(layer))
         k_slab, v_slab = self.kv.get_kv_buffer(layer)
+        new = {}
+        if self.writes_kv:
+            new = dict(k_new=self.k[layer], v_new=self.v_rows(layer), out_cache_loc=self.loc,
+                       fuse_kv_write=not self.args.no_fuse)
         hip.paged_decode(
             self.q[layer], k_slab, v_slab, self.r2t.req_to_token, self.req, self.local_seq,
             n_splits=self.n_splits, variant=self.args.variant, out=self.out, lse=self.lse,
-            workspace=self.workspace,
+            workspace=self.workspace, **new,
         )
         if self.layout.world > 1:
             self.full_out = self.pkg.tp_attention_exchange(self.layout, self.out, self.lse, tp_group, self.dtype)

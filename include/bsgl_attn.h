@@ -43,10 +43,16 @@ extern "C" {
 #define BSGL_DTYPE_F16 1
 #define BSGL_DTYPE_F32 2
 
-/* decode kernel selection (bsgl_paged_decode `variant`) */
+/* decode kernel selection (low byte of bsgl_paged_decode `variant`) */
 #define BSGL_DECODE_AUTO 0
 #define BSGL_DECODE_VALU 1 /* generic: any dtype, head_dim 64/128, group <= 8 */
-#define BSGL_DECODE_MFMA 2 /* bf16/f16: QK^T on matrix cores */
+#define BSGL_DECODE_MFMA 2 /* bf16/f16, head_dim 128: QK^T and PV on matrix cores */
+/* flag or-ed into `variant`: the caller asserts that every slot in out_cache_loc
+ * is referenced by no page-table row other than its own request's (what the
+ * reference scheduler produces: scheduler.py:459-490 hands out fresh slots).
+ * The KV write may then be fused into the decode kernel instead of being a
+ * launch of its own; without the flag the write is always a separate launch. */
+#define BSGL_DECODE_FUSE_KV_WRITE 0x100
 
 /* ABI version of this header (bumped on any signature change). */
 int bsgl_abi_version(void);
@@ -77,6 +83,7 @@ int bsgl_kv_scatter(void* k_slab /*device*/, void* v_slab /*device*/,
 int32_t bsgl_decode_num_splits(int32_t batch, int32_t n_kv_heads, int32_t max_context_len);
 size_t bsgl_decode_workspace_bytes(int32_t batch, int32_t n_q_heads, int32_t head_dim,
                                    int32_t n_splits, int32_t out_is_f32);
+size_t bsgl_decode_counter_bytes(void);
 
 /*
  * Paged decode attention, one query row per request.  Replaces
@@ -94,11 +101,24 @@ size_t bsgl_decode_workspace_bytes(int32_t batch, int32_t n_q_heads, int32_t hea
  * bsgl_merge_attn_states.  n_splits comes from bsgl_decode_num_splits (or any
  * value in [1, 64]); workspace holds bsgl_decode_workspace_bytes bytes and may
  * be NULL when that is 0 (one split, out_dtype == dtype).
+ *
+ * k_new / v_new / out_cache_loc (all three or none, NULL = none): the new
+ * token's rows, [batch, n_kv_heads * head_dim] with the given row strides, to be
+ * stored at slab slot out_cache_loc[i] BEFORE attention reads the cache -- the
+ * set_kv_buffer call the reference makes first (attn_backend.py:20-23).
+ *
+ * Workspace contract: its first bsgl_decode_counter_bytes() bytes (a constant)
+ * hold the tickets of the in-kernel split merge.  They must be zero when a
+ * workspace is first used; every call leaves them zero.  Two calls that may run
+ * concurrently (different streams) need different workspaces.
  */
 int bsgl_paged_decode(void* out /*device*/, int64_t out_row_stride,
                       float* lse /*device or NULL*/,
                       const void* q /*device*/, int64_t q_row_stride,
-                      const void* k_slab /*device*/, const void* v_slab /*device*/,
+                      const void* k_new /*device or NULL*/, const void* v_new /*device or NULL*/,
+                      int64_t k_new_row_stride, int64_t v_new_row_stride,
+                      const int32_t* out_cache_loc /*device or NULL, [batch]*/,
+                      void* k_slab /*device*/, void* v_slab /*device*/,
                       int64_t slab_row_stride, int64_t n_slots,
                       const int32_t* req_to_token /*device*/, int64_t table_row_stride,
                       int64_t table_rows, int64_t table_cols,

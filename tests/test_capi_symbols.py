@@ -30,10 +30,12 @@ def test_symbol_exported(name):
 
 def test_host_arithmetic():
     assert _hip.lib.bsgl_abi_version() == _hip.ABI_VERSION
-    assert _hip.decode_num_splits(64, 2, 4096) >= 4
+    assert _hip.decode_num_splits(64, 2, 4096) == 8  # 64 requests x 2 kv heads x 8 = 1024 workgroups
+    assert _hip.decode_num_splits(64, 1, 4096) == 16
     assert _hip.decode_num_splits(4096, 2, 4096) == 1
     assert _hip.decode_num_splits(1, 2, 100) == 1  # one short request: a single chunk
     assert _hip.decode_workspace_bytes(64, 12, 128, 1) == 0
+    assert _hip.lib.bsgl_decode_counter_bytes() >= 64 * 2 * 4
     assert _hip.decode_workspace_bytes(64, 12, 128, 1, True) >= 64 * 12 * 129 * 4
     assert _hip.decode_workspace_bytes(64, 12, 128, 8) >= 8 * 64 * 12 * 129 * 4
     assert _hip.prefill_workspace_bytes(3, 100, 12, 128) >= (3 + 1) * 8 + 2 * 100 * 8
@@ -41,7 +43,8 @@ def test_host_arithmetic():
 
 def test_bad_arguments_are_rejected_on_the_host():
     lib = _hip.lib
-    rc = lib.bsgl_paged_decode(None, 0, None, None, 0, None, None, 0, 0, None, 0, 0, 0, None, None,
+    rc = lib.bsgl_paged_decode(None, 0, None, None, 0, None, None, 0, 0, None,
+                               None, None, 0, 0, None, 0, 0, 0, None, None,
                                4, 12, 2, 128, 0.1, 0, 0, 1, 0, None, 0, None)
     assert rc == _hip.BSGL_ERR_BAD_ARG and b"null" in lib.bsgl_last_error()
     rc = lib.bsgl_kv_scatter(None, None, 0, 0, None, None, None, 0, 0, 3, 2, 128, 7, None)

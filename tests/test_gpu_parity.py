@@ -186,6 +186,51 @@ def test_decode_random_ragged(gpu, dtype, hq, hkv, dim, variant):
         assert torch.allclose(lse.double().cpu(), want_lse, rtol=1e-4, atol=2e-3 if dtype != torch.float32 else 1e-4)
 
 
+@pytest.mark.parametrize("dtype,hq,hkv", [(torch.bfloat16, 12, 2), (torch.float16, 28, 4), (torch.bfloat16, 6, 1)])
+def test_fused_kv_write_and_merge(gpu, dtype, hq, hkv, monkeypatch):
+    """The decode kernel that stores the new token itself and merges its own
+    splits must agree bit for bit with the three-launch form (scatter kernel,
+    decode, merge kernel) on output, lse and slab contents -- twice in a row on
+    one workspace, the second call with fewer requests."""
+    from baby_sglang_amd import _hip
+
+    dim = 128
+    seq_lens = [1, 16, 17, 333, 64, 1500, 129]
+    cpu, r2t, kv = random_decode_problem(gpu, dtype, hq, hkv, dim, seq_lens, seed=99 + hq)
+    gen = torch.Generator().manual_seed(5)
+    k_new = torch.randn((len(seq_lens), hkv, dim), generator=gen).to(dtype).to(gpu)
+    qkv = torch.randn((len(seq_lens), (hq + 2 * hkv) * dim), generator=gen).to(dtype).to(gpu)
+    v_new = qkv[:, (hq + hkv) * dim :].view(len(seq_lens), hkv, dim)  # strided rows
+    rows, seq = cpu["req_pool_indices"].to(gpu), cpu["seq_lens"].to(gpu)
+    loc = r2t.req_to_token[rows, seq - 1].contiguous()
+    q = cpu["q"].to(gpu)
+    ws = _hip.new_decode_workspace(_hip.decode_workspace_bytes(len(seq_lens), hq, dim, 7), gpu)
+    for n_req in (len(seq_lens), 3):
+        results = []
+        for fused in (True, False):
+            kv.k_buffer[0].copy_(cpu["k_slab"])
+            kv.v_buffer[0].copy_(cpu["v_slab"])
+            monkeypatch.setenv("BSGL_NO_FUSED_MERGE", "0" if fused else "1")
+            k_slab, v_slab = kv.get_kv_buffer(0)
+            lse = torch.empty((n_req, hq), dtype=torch.float32, device=gpu)
+            out = _hip.paged_decode(q[:n_req], k_slab, v_slab, r2t.req_to_token, rows[:n_req], seq[:n_req],
+                                    n_splits=7, variant=2, lse=lse, workspace=ws,
+                                    k_new=k_new[:n_req], v_new=v_new[:n_req], out_cache_loc=loc[:n_req],
+                                    fuse_kv_write=fused)
+            torch.cuda.synchronize()
+            results.append((out.clone(), lse.clone(), k_slab.clone(), v_slab.clone()))
+        for a, b in zip(*results):
+            assert torch.equal(a, b)
+        # tickets are back at zero for the next call
+        assert int(ws[: _hip.lib.bsgl_decode_counter_bytes()].max()) == 0
+        # and the result is right
+        k_ref, v_ref = cpu["k_slab"].clone(), cpu["v_slab"].clone()
+        orc.kv_scatter_ref(k_ref, v_ref, loc[:n_req].cpu(), k_new[:n_req].cpu(), v_new[:n_req].cpu())
+        want = orc.decode_exact(cpu["q"][:n_req], k_ref, v_ref, cpu["req_to_token"], rows[:n_req].cpu(), seq[:n_req].cpu())
+        assert_close(results[0][0], want, dtype, "fused decode")
+        assert torch.equal(results[0][2].cpu(), k_ref) and torch.equal(results[0][3].cpu(), v_ref)
+
+
 def test_decode_empty_and_zero_length(gpu):
     from baby_sglang_amd import _hip
 

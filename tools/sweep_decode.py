@@ -65,7 +65,7 @@ def main():
                     wl.n_splits = splits
                     ws = pkg._hip.decode_workspace_bytes(args.batch, wl.hq_l, wl.dim, splits, False)
                     if wl.workspace.numel() < ws:
-                        wl.workspace = torch.empty(ws, dtype=torch.uint8, device=dev)
+                        wl.workspace = pkg._hip.new_decode_workspace(ws, dev)
                     got = pkg._hip.paged_decode(wl.q[0], k_slab, v_slab, wl.r2t.req_to_token, wl.req, wl.local_seq,
                                                 n_splits=splits, variant=variant, workspace=wl.workspace).float()
                     err = (got - ref).abs().max().item()
