@@ -161,20 +161,30 @@ def barrier(world):
         torch.distributed.barrier()
 
 
+LAST_EVENT_MS = [0.0]
+
+
 def timed_steps(fn, steps, warmup, world):
-    """Barrier + device sync on both sides; wall time of exactly `steps` calls; max over ranks."""
+    """Barrier + device sync on both sides; wall time of exactly `steps` calls; max over
+    ranks.  A HIP event pair on the launch stream brackets the same region
+    (LAST_EVENT_MS): device time of the steps without the host-side sync cost."""
     for _ in range(warmup):
         fn()
+    stream = torch.cuda.current_stream()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     barrier(world)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    ev0.record(stream)
     for _ in range(steps):
         fn()
+    ev1.record(stream)
     torch.cuda.synchronize()
     barrier(world)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    LAST_EVENT_MS[0] = ev0.elapsed_time(ev1)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -296,6 +306,7 @@ def main():
         args.mode = "eager"  # collectives are issued by torch.distributed from Python each layer
     runner = make_runner(wl, args.mode, tp_group)
     dt = timed_steps(runner, args.steps, args.warmup, world)
+    event_ms_per_step = LAST_EVENT_MS[0] / args.steps
     ms_per_step = dt / args.steps * 1e3
     tokens_per_s = args.batch * args.steps / dt
 
@@ -327,8 +338,16 @@ def main():
     }
 
     if rank == 0 or world > 1:
-        # per-launch event timing of the dominant kernel, on every rank (keeps ranks in step), reported by rank 0
-        ev_ms = kernel_event_times(wl, max(2, min(args.steps, 10)))
+        # Dominant kernel = the decode kernel, launched once per layer (it also stores the new
+        # token and merges its splits).  Its average launch duration is the HIP-event time of the
+        # timed region divided by the launches in it; at one GPU the region holds nothing else, so
+        # this is the kernel time plus the ~1.5 us boundary between dependent launches (an upper
+        # bound on what rocprofv3 reports for the kernel alone).  With several GPUs the region also
+        # holds the collectives, so the launches are timed on their own there.
+        if world == 1:
+            ev_ms = event_ms_per_step / args.layers
+        else:
+            ev_ms = kernel_event_times(wl, max(2, min(args.steps, 10)))
         total_b, kv_b = wl.algorithmic_bytes_per_layer()
         achieved = total_b / (ev_ms * 1e-3) / 1e9
         result["roofline"] = {
@@ -338,7 +357,9 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": read_traffic() if world == 1 else None,
-            "kernel": "paged decode (split-KV kernel + merge), one layer, HIP events around each launch",
+            "kernel": "decode_mfma_kernel (paged decode of one layer incl. new-token KV write and split merge); "
+                      "HIP events over the timed region / launches" if world == 1 else
+                      "decode launches of one layer, HIP events around each call",
             "algorithmic_bytes_per_launch": total_b,
             "kv_bytes_per_launch": kv_b,
             "avg_launch_us": ev_ms * 1e3,

@@ -1,0 +1,127 @@
+"""Tensor-parallel runtime on CPU: two gloo ranks (no GPU).  Covers the four
+reference wrappers (tp_runtime.py:10-51) and the attention sharding / exchange:
+head sharding (world == kv heads) and sequence slicing (world > kv heads), each
+checked against the unsharded float64 oracle."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _merge_fn(parts_o, parts_lse, dtype):
+    from oracle import attn_oracle as orc
+
+    out, _ = orc.merge_states_exact(parts_o, parts_lse)
+    return out.to(dtype)
+
+
+def _worker(rank, world, port, n_kv_heads):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from baby_sglang_amd import tp_runtime as tp
+    from oracle import attn_oracle as orc
+
+    r, w, group = tp.init_tp(backend="gloo")
+    assert (r, w) == (rank, world)
+
+    # --- the four wrappers
+    x = torch.full((3,), float(rank + 1))
+    assert tp.tp_all_reduce_sum(x, group) is x and x.tolist() == [3.0] * 3
+    g = tp.tp_all_gather(torch.full((2, 2), float(rank)), group)
+    assert tuple(g.shape) == (4, 2) and g[:2].eq(0).all() and g[2:].eq(1).all()
+    b = torch.tensor([7.0 if rank == 1 else 0.0])
+    assert tp.tp_broadcast(b, 1, group) is b and b.item() == 7.0
+
+    # --- sharded decode attention == unsharded
+    hq, dim = 4 * n_kv_heads, 64
+    layout = tp.TPLayout(rank, world, hq, n_kv_heads)
+    gen = torch.Generator().manual_seed(0)  # same data on both ranks
+    seq_lens = [5, 12, 1, 9]
+    n_slots = sum(seq_lens) + 1
+    k_slab = torch.randn((n_slots, n_kv_heads, dim), generator=gen)
+    v_slab = torch.randn((n_slots, n_kv_heads, dim), generator=gen)
+    q = torch.randn((len(seq_lens), hq, dim), generator=gen)
+    table = torch.zeros((len(seq_lens), 16), dtype=torch.int32)
+    perm = torch.randperm(n_slots - 1, generator=gen) + 1
+    used = 0
+    for i, n in enumerate(seq_lens):
+        table[i, :n] = perm[used : used + n].to(torch.int32)
+        used += n
+    rows = torch.arange(len(seq_lens))
+    seq = torch.tensor(seq_lens)
+    full = orc.decode_exact(q, k_slab, v_slab, table, rows, seq)
+
+    # this rank's shard: its kv heads, and every tp_seq-th position starting at seq_rank
+    local_table = torch.zeros_like(table)
+    local_len = layout.local_len(seq)
+    for i, n in enumerate(seq_lens):
+        mine = table[i, :n][layout.seq_rank :: layout.tp_seq]
+        assert len(mine) == int(local_len[i])
+        local_table[i, : len(mine)] = mine
+    o, lse = orc.decode_exact(layout.shard_q(q), layout.shard_kv(k_slab), layout.shard_kv(v_slab),
+                              local_table, rows, local_len, return_lse=True)
+    assert o.shape[1] == layout.local_q_heads * dim
+    if layout.tp_seq == 1:
+        got = tp.tp_attention_exchange(layout, o, None, group, torch.float64)
+    else:
+        got = tp.tp_attention_exchange(layout, o.float(), lse.float(), group, torch.float64, merge_fn=_merge_fn)
+    assert tuple(got.shape) == tuple(full.shape)
+    tol = 1e-12 if layout.tp_seq == 1 else 2e-6  # the sequence-sliced state travels as fp32
+    assert (got - full).abs().max().item() < tol
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_kv_heads", [2, 1])
+def test_two_ranks(n_kv_heads):
+    mp.spawn(_worker, args=(2, _free_port(), n_kv_heads), nprocs=2, join=True)
+
+
+def test_layouts():
+    import sys
+
+    sys.path.insert(0, ROOT)
+    from baby_sglang_amd.tp_runtime import TPLayout
+
+    # Qwen2.5-1.5B: 12 q heads, 2 kv heads
+    for world, (tp_kv, tp_seq) in {1: (1, 1), 2: (2, 1), 4: (2, 2), 8: (2, 4)}.items():
+        seen = set()
+        for rank in range(world):
+            lay = TPLayout(rank, world, 12, 2)
+            assert (lay.tp_kv, lay.tp_seq) == (tp_kv, tp_seq)
+            assert lay.local_q_heads == 12 // tp_kv and lay.local_kv_heads == 2 // tp_kv
+            seen.add((lay.kv_head_range, lay.seq_rank))
+            lens = torch.tensor([0, 1, 7, 2048])
+            total = sum(TPLayout(r, world, 12, 2).local_len(lens) for r in range(world) if r // tp_seq == lay.kv_rank)
+            assert total.tolist() == lens.tolist()
+        assert len(seen) == world
+    with pytest.raises(ValueError):
+        TPLayout(0, 3, 12, 2)  # 3 neither divides nor is a multiple of 2 kv heads
+    with pytest.raises(ValueError):
+        TPLayout(5, 4, 12, 2)
+
+
+def test_world_of_one_needs_no_process_group():
+    import sys
+
+    sys.path.insert(0, ROOT)
+    from baby_sglang_amd import tp_runtime as tp
+
+    x = torch.ones(2)
+    assert tp.tp_all_reduce_sum(x, None) is x
+    assert tp.tp_all_gather(x, None) is x
+    assert tp.tp_broadcast(x, 0, None) is x
