@@ -89,9 +89,33 @@ struct ExpandArgs {
   const int64_t* extended_lens;
   int32_t batch;
   int32_t total_q_tokens;
-  int64_t* cu_ext;   // [batch + 1]
-  int64_t* row_req;  // [total_q_tokens]
+  int64_t* cu_ext;   // [batch + 1] running sum of extended_lens
+  int64_t* cu_blk;   // [batch + 1] running sum of ceil(extended_lens / 16); may be NULL
+  int64_t* row_req;  // [total_q_tokens]; may be NULL (then only the running sums are made)
   int64_t* row_len;  // [total_q_tokens]
+};
+
+// extend attention over blocks of 16 query positions (matrix-core kernel)
+struct PrefillArgs {
+  void* out;
+  int64_t out_row_stride;
+  const void* q;
+  int64_t q_row_stride;
+  PagedKV kv;
+  const int64_t* req_idx;
+  const int64_t* seq_lens;
+  const int64_t* prefix_lens;
+  const int64_t* extended_lens;
+  const int64_t* cu_ext;
+  const int64_t* cu_blk;
+  int32_t batch;
+  int32_t total_q_tokens;
+  int32_t max_blocks;  // grid bound: ceil(total_q_tokens / 16) + batch
+  int32_t n_q_heads;
+  int32_t n_kv_heads;
+  int32_t head_dim;
+  float scale;
+  int32_t dtype;
 };
 
 inline bool decode_direct_out(const DecodeArgs& a) { return a.n_splits == 1 && a.out_dtype == a.dtype; }
@@ -106,5 +130,8 @@ hipError_t launch_decode_mfma(const DecodeArgs& a, hipStream_t stream);
 hipError_t launch_merge(const MergeArgs& a, hipStream_t stream);
 hipError_t launch_kv_scatter(const ScatterArgs& a, hipStream_t stream);
 hipError_t launch_prefill_expand(const ExpandArgs& a, hipStream_t stream);
+
+bool prefill_mfma_supported(const PrefillArgs& a, const char** why);
+hipError_t launch_prefill_mfma(const PrefillArgs& a, hipStream_t stream);
 
 }  // namespace bsgl

@@ -264,7 +264,7 @@ size_t bsgl_prefill_workspace_bytes(int32_t batch, int32_t total_q_tokens, int32
   if (batch <= 0 || total_q_tokens <= 0) return 0;
   // cu_ext[batch + 1], row_req[T], row_len[T], then split partials sized for the
   // worst case over context lengths (64 splits only when T is tiny)
-  size_t bytes = align_up((size_t)(batch + 1) * 8, 256) + 2 * align_up((size_t)total_q_tokens * 8, 256);
+  size_t bytes = 2 * align_up((size_t)(batch + 1) * 8, 256) + 2 * align_up((size_t)total_q_tokens * 8, 256);
   const int32_t splits = prefill_row_splits(total_q_tokens, 1 << 30);
   bytes += bsgl_decode_workspace_bytes(total_q_tokens, n_q_heads, head_dim, splits, 0);
   return bytes;
@@ -299,10 +299,48 @@ int bsgl_paged_prefill(void* out, int64_t out_row_stride, const void* q, int64_t
   ex.total_q_tokens = total_q_tokens;
   ex.cu_ext = (int64_t*)ws;
   ws += align_up((size_t)(batch + 1) * 8, 256);
+  ex.cu_blk = (int64_t*)ws;
+  ws += align_up((size_t)(batch + 1) * 8, 256);
   ex.row_req = (int64_t*)ws;
   ws += align_up((size_t)total_q_tokens * 8, 256);
   ex.row_len = (int64_t*)ws;
   ws += align_up((size_t)total_q_tokens * 8, 256);
+
+  // matrix-core kernel over blocks of 16 query positions when the shape allows it
+  bsgl::PrefillArgs pa{};
+  pa.out = out;
+  pa.out_row_stride = out_row_stride;
+  pa.q = q;
+  pa.q_row_stride = q_row_stride;
+  pa.kv = a.kv;
+  pa.req_idx = req_pool_indices;
+  pa.seq_lens = seq_lens;
+  pa.prefix_lens = prefix_lens;
+  pa.extended_lens = extended_lens;
+  pa.cu_ext = ex.cu_ext;
+  pa.cu_blk = ex.cu_blk;
+  pa.batch = batch;
+  pa.total_q_tokens = total_q_tokens;
+  pa.max_blocks = (total_q_tokens + 15) / 16 + batch;
+  pa.n_q_heads = n_q_heads;
+  pa.n_kv_heads = n_kv_heads;
+  pa.head_dim = head_dim;
+  pa.scale = scale;
+  pa.dtype = dtype;
+  const char* why = "";
+  const int32_t kind = variant & 0xff;
+  if (kind != BSGL_DECODE_AUTO && kind != BSGL_DECODE_VALU && kind != BSGL_DECODE_MFMA)
+    return fail(BSGL_ERR_BAD_ARG, "unknown variant %d", variant);
+  const bool mfma_ok = bsgl::prefill_mfma_supported(pa, &why);
+  if (kind == BSGL_DECODE_MFMA && !mfma_ok) return fail(BSGL_ERR_UNSUPPORTED, "matrix-core extend: %s", why);
+  if (kind != BSGL_DECODE_VALU && mfma_ok) {
+    ex.row_req = nullptr;  // only the running sums are needed
+    hipError_t e = bsgl::launch_prefill_expand(ex, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail("prefill running-sum launch", e);
+    e = bsgl::launch_prefill_mfma(pa, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail("prefill launch", e);
+    return BSGL_OK;
+  }
   hipError_t e = bsgl::launch_prefill_expand(ex, (hipStream_t)stream);
   if (e != hipSuccess) return hip_fail("prefill expand launch", e);
 
@@ -327,7 +365,6 @@ int bsgl_paged_prefill(void* out, int64_t out_row_stride, const void* q, int64_t
   const size_t cb = kCounterBytes;
   a.ws_o = (float*)(ws + cb);
   a.ws_lse = splits > 1 ? (float*)(ws + cb + align_up((size_t)splits * rh * (size_t)head_dim * 4, 256)) : nullptr;
-  (void)variant;
   return run_decode(a, BSGL_DECODE_VALU, nullptr, (hipStream_t)stream);
 }
 

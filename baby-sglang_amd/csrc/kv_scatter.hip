@@ -31,30 +31,42 @@ __global__ __launch_bounds__(256) void kv_scatter_kernel(ScatterArgs a) {
   *(uint4*)((char*)a.v_slab + dst) = vv;
 }
 
-// exclusive running sum of extended_lens (negative lengths count as 0)
+// exclusive running sums of extended_lens and of ceil(extended_lens / 16)
+// (negative lengths count as 0)
 __global__ void prefill_cu_kernel(ExpandArgs a) {
-  __shared__ int64_t s_part[256];
+  __shared__ int64_t s_ext[256], s_blk[256];
   const int tid = threadIdx.x;
   const int per = (a.batch + 255) / 256;
   const int lo = min(tid * per, a.batch), hi = min(lo + per, a.batch);
-  int64_t sum = 0;
-  for (int i = lo; i < hi; ++i) sum += max((int64_t)0, a.extended_lens[i]);
-  s_part[tid] = sum;
+  int64_t sum = 0, blocks = 0;
+  for (int i = lo; i < hi; ++i) {
+    const int64_t e = max((int64_t)0, a.extended_lens[i]);
+    sum += e;
+    blocks += (e + 15) / 16;
+  }
+  s_ext[tid] = sum;
+  s_blk[tid] = blocks;
   __syncthreads();
   if (tid == 0) {
-    int64_t run = 0;
+    int64_t run = 0, brun = 0;
     for (int i = 0; i < 256; ++i) {
-      const int64_t v = s_part[i];
-      s_part[i] = run;
+      const int64_t v = s_ext[i], b = s_blk[i];
+      s_ext[i] = run;
+      s_blk[i] = brun;
       run += v;
+      brun += b;
     }
     a.cu_ext[a.batch] = run;
+    if (a.cu_blk != nullptr) a.cu_blk[a.batch] = brun;
   }
   __syncthreads();
-  int64_t run = s_part[tid];
+  int64_t run = s_ext[tid], brun = s_blk[tid];
   for (int i = lo; i < hi; ++i) {
+    const int64_t e = max((int64_t)0, a.extended_lens[i]);
     a.cu_ext[i] = run;
-    run += max((int64_t)0, a.extended_lens[i]);
+    if (a.cu_blk != nullptr) a.cu_blk[i] = brun;
+    run += e;
+    brun += (e + 15) / 16;
   }
 }
 
@@ -95,7 +107,7 @@ hipError_t launch_kv_scatter(const ScatterArgs& a, hipStream_t stream) {
 hipError_t launch_prefill_expand(const ExpandArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL(prefill_cu_kernel, dim3(1), dim3(256), 0, stream, a);
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess || a.total_q_tokens == 0) return e;
+  if (e != hipSuccess || a.total_q_tokens == 0 || a.row_req == nullptr) return e;
   hipLaunchKernelGGL(prefill_rows_kernel, dim3((a.total_q_tokens + 255) / 256), dim3(256), 0, stream, a);
   return hipGetLastError();
 }

@@ -40,108 +40,13 @@
 // are zero before and after every launch.
 #include "bsgl_device.h"
 #include "bsgl_launch.h"
+#include "bsgl_mfma.h"
 
 namespace bsgl {
 
 namespace {
 
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
-typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
-
-constexpr int kTile = 16;        // tokens per tile (= MFMA M of the score product)
-constexpr int kSlotBlock = 512;  // page-table entries staged in LDS at a time
-
-template <typename Tag> struct Mma;
-template <> struct Mma<bf16_tag> {
-  __device__ static __forceinline__ f32x4 qk(const uint4& k, const uint4& q, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, k), __builtin_bit_cast(bf16x8_t, q), c, 0, 0, 0);
-  }
-  __device__ static __forceinline__ f32x4 pv(const uint2& p, const s16x4_t& v, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, p), v, c, 0, 0, 0);
-  }
-};
-template <> struct Mma<f16_tag> {
-  __device__ static __forceinline__ f32x4 qk(const uint4& k, const uint4& q, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, k), __builtin_bit_cast(f16x8_t, q), c, 0, 0, 0);
-  }
-  __device__ static __forceinline__ f32x4 pv(const uint2& p, const s16x4_t& v, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_t, p), __builtin_bit_cast(f16x4_t, v), c, 0, 0, 0);
-  }
-};
-
-__device__ __forceinline__ constexpr int rec_of_token(int t) { return (t & 3) | ((t & 4) << 1) | ((t & 8) >> 1); }
-__device__ __forceinline__ constexpr int xr_of_rec(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
-
-// One LDS-DMA instruction: 64 lanes x 16 B from per-lane global addresses to
-// LDS bytes [lds_dst, lds_dst + 1024), lane-linear.  M0 carries the LDS address
-// and is restored, the compiler does not see the LDS write or count the load:
-// completion is awaited with dma_wait<N>() below.
-template <bool NT>
-__device__ __forceinline__ void dma_1k(const void* gsrc, uint32_t lds_dst) {
-  uint32_t keep;
-  if constexpr (NT) {  // non-temporal: K/V bytes are read once per step
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off nt\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_dst)
-        : "memory");
-  } else {
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_dst)
-        : "memory");
-  }
-}
-
-// max / sum over the four lanes {l, l^16, l^32, l^48} (the lane groups that share a
-// q head), every lane receiving the result: two half exchanges on the vector ALU.
-// v_permlane32_swap a, b: lanes 32-63 of a trade places with lanes 0-31 of b;
-// v_permlane16_swap a, b: the odd 16-lane rows of a with the even rows of b.
-// Written in assembly with both registers as read-write operands: with
-// __builtin_amdgcn_permlane{16,32}_swap hipcc (ROCm 7.2) folds the two results of
-// one call into the same register in expressions such as max(r[0], r[1]).
-// s_nop 1 = the two wait states a VALU write needs before the swap reads it.
-__device__ __forceinline__ void swap32(float& a, float& b) {
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-}
-__device__ __forceinline__ void swap16(float& a, float& b) {
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-}
-__device__ __forceinline__ float quad_group_max(float x) {
-  float a = x, b = x;
-  swap32(a, b);
-  a = fmaxf(a, b);
-  b = a;
-  swap16(a, b);
-  return fmaxf(a, b);
-}
-__device__ __forceinline__ float quad_group_sum(float x) {
-  float a = x, b = x;
-  swap32(a, b);
-  a = a + b;
-  b = a;
-  swap16(a, b);
-  return a + b;
-}
-
-// wait until at most N of this wave's vector-memory operations are outstanding
-template <int N> __device__ __forceinline__ void dma_wait() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
+using namespace mfma;
 
 template <typename Tag, int HPT, int NSTAGE, bool NT>
 __global__ __launch_bounds__(64) void decode_mfma_kernel(DecodeArgs a) {
@@ -342,12 +247,13 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(DecodeArgs a) {
           l_run[hh] += pr[r];
         }
         // P as the A operand of the 16x16x16 product: lane (q, g) holds P[q][token 4 g + j]
-        const uint2 pf = make_uint2(E::pack2(pr[0], pr[1]), E::pack2(pr[2], pr[3]));
+        const PFrag<Tag> pf(pr);
 #pragma unroll
         for (int n = 0; n < 8; ++n) {
           const s16x4_t vf = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (__attribute__((address_space(3))) s16x4_t*)(st + hh * 256 + v_off[n]));
-          o_acc[hh][n] = Mma<Tag>::pv(pf, vf, o_acc[hh][n]);
+#pragma unroll
+          for (int k = 0; k < PFrag<Tag>::N; ++k) o_acc[hh][n] = Mma<Tag>::pv(pf.f[k], vf, o_acc[hh][n]);
         }
       }
     }
