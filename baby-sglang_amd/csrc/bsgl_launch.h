@@ -90,7 +90,8 @@ struct ExpandArgs {
   int32_t batch;
   int32_t total_q_tokens;
   int64_t* cu_ext;   // [batch + 1] running sum of extended_lens
-  int64_t* cu_blk;   // [batch + 1] running sum of ceil(extended_lens / 16); may be NULL
+  int64_t* cu_blk;   // [batch + 1] running sum of ceil(extended_lens / blk_rows); may be NULL
+  int32_t blk_rows;  // 16 or 64 (0 counts as 16)
   int64_t* row_req;  // [total_q_tokens]; may be NULL (then only the running sums are made)
   int64_t* row_len;  // [total_q_tokens]
 };
@@ -110,7 +111,8 @@ struct PrefillArgs {
   const int64_t* cu_blk;
   int32_t batch;
   int32_t total_q_tokens;
-  int32_t max_blocks;  // grid bound: ceil(total_q_tokens / 16) + batch
+  int32_t blk_rows;    // query positions per workgroup: 16 or 64
+  int32_t max_blocks;  // grid bound: ceil(total_q_tokens / blk_rows) + batch
   int32_t n_q_heads;
   int32_t n_kv_heads;
   int32_t head_dim;

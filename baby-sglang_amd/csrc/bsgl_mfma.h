@@ -19,8 +19,12 @@ typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
 constexpr int kTile = 16;        // tokens per tile (= MFMA M of the score product)
 constexpr int kSlotBlock = 512;  // page-table entries staged in LDS at a time
 
+// qk / pv32: 16x16x32 products (8 k-values per lane); pv: the 16x16x16 form (4 per lane).
 template <typename Tag> struct Mma;
 template <> struct Mma<bf16_tag> {
+  __device__ static __forceinline__ f32x4 pv32(const uint4& p, const uint4& v, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, p), __builtin_bit_cast(bf16x8_t, v), c, 0, 0, 0);
+  }
   __device__ static __forceinline__ f32x4 qk(const uint4& k, const uint4& q, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, k), __builtin_bit_cast(bf16x8_t, q), c, 0, 0, 0);
   }
@@ -29,6 +33,9 @@ template <> struct Mma<bf16_tag> {
   }
 };
 template <> struct Mma<f16_tag> {
+  __device__ static __forceinline__ f32x4 pv32(const uint4& p, const uint4& v, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, p), __builtin_bit_cast(f16x8_t, v), c, 0, 0, 0);
+  }
   __device__ static __forceinline__ f32x4 qk(const uint4& k, const uint4& q, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, k), __builtin_bit_cast(f16x8_t, q), c, 0, 0, 0);
   }

@@ -290,7 +290,7 @@ int bsgl_paged_prefill(void* out, int64_t out_row_stride, const void* q, int64_t
     return fail(BSGL_ERR_WORKSPACE, "prefill needs a 16-byte aligned workspace of %zu bytes (got %zu)", need, workspace ? workspace_bytes : (size_t)0);
 
   char* ws = (char*)workspace;
-  bsgl::ExpandArgs ex;
+  bsgl::ExpandArgs ex{};
   ex.req_pool_indices = req_pool_indices;
   ex.seq_lens = seq_lens;
   ex.prefix_lens = prefix_lens;
@@ -321,7 +321,11 @@ int bsgl_paged_prefill(void* out, int64_t out_row_stride, const void* q, int64_t
   pa.cu_blk = ex.cu_blk;
   pa.batch = batch;
   pa.total_q_tokens = total_q_tokens;
-  pa.max_blocks = (total_q_tokens + 15) / 16 + batch;
+  // 64 query positions per workgroup unless the extends are very short on average
+  pa.blk_rows = (int64_t)total_q_tokens >= 24ll * batch ? 64 : 16;
+  if (env_int("BSGL_PREFILL_BLK", 0) == 16 || env_int("BSGL_PREFILL_BLK", 0) == 64) pa.blk_rows = env_int("BSGL_PREFILL_BLK", 0);
+  ex.blk_rows = pa.blk_rows;
+  pa.max_blocks = (total_q_tokens + pa.blk_rows - 1) / pa.blk_rows + batch;
   pa.n_q_heads = n_q_heads;
   pa.n_kv_heads = n_kv_heads;
   pa.head_dim = head_dim;

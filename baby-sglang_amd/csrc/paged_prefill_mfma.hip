@@ -5,16 +5,24 @@
 // 0 .. prefix_lens[i] + r of its own sequence (the additive -inf mask of
 // attn_backend.py:74-92 as a comparison), K/V gathered through the page table.
 //
-// One workgroup = one wave = (16 consecutive extend positions of one request) x
+// One workgroup = WAVES waves (4, or 1 for batches of very short extends); a wave owns
+// 16 consecutive extend positions of one request, the workgroup 16 * WAVES of them, x
 // (one kv head) x (up to RT q heads of that kv head's GQA group; a group larger
 // than 4 heads is split over two workgroups so accumulators and Q fragments stay
 // in registers): the score tiles of a K/V tile reuse the same K fragments
 // (ds_read_b128) and the same transposed V fragments (ds_read_b64_tr_b16), so a
 // K/V byte is fetched once per 16 positions for RT q heads instead of once per head.  The streaming side
 // is the decode kernel's: page-table entries -> 32-bit row offsets in LDS, LDS-DMA
-// gather of 16-token tiles into a private ring behind a counted s_waitcnt, online
-// softmax in base 2 on the accumulator layout (a lane owns one query position and 4
-// tokens), P fed to the PV product straight from the score accumulator.
+// gather of 16-token tiles into a ring behind a counted s_waitcnt, online softmax in
+// base 2 on the accumulator layout, P fed to the PV product straight from the score
+// accumulator.  A step covers TWO tiles (32 tokens): a lane then owns one query
+// position and 4 + 4 tokens, which is exactly the 8 k-values per lane of a 16x16x32
+// product -- the summation order over tokens is free as long as P and V^T agree on
+// it, so the two tiles' probability fragments and transposed V fragments are simply
+// concatenated and PV runs at the full-rate 16x16x32 shape.  The waves of a
+// workgroup share every K/V step: each issues a quarter of its DMA, waits for its
+// own share, and one barrier per step both publishes it and retires the stage that
+// the step after next will overwrite (3-stage ring).
 //
 // Work list without a host read: prefill_cu_kernel writes the running sums of
 // extended_lens and of ceil(extended_lens / 16); workgroup b finds its request by
@@ -29,41 +37,57 @@ namespace {
 
 using namespace mfma;
 
-template <typename Tag, int RT, int NSTAGE>
-__global__ __launch_bounds__(64) void prefill_mfma_kernel(PrefillArgs a) {
+// Register budget: 512 / waves-per-SIMD.  Two heads per workgroup fit two waves per
+// SIMD (256 registers), one head three; four heads need the whole file.  (The
+// single-wave kernel is limited by its private ring in LDS, not by registers.)
+template <typename Tag, int RT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES == 1 || RT > 2 ? 1 : RT == 1 ? 3 : 2)))
+void prefill_mfma_kernel(PrefillArgs a) {
   using E = Elem<Tag>;
   constexpr int D = 128;
   constexpr int REC = 512;  // K row | V row of one kv head
+  constexpr int NSTAGE = 3;
   constexpr int TILE_BYTES = kTile * REC;
-  constexpr int DMA_PER_TILE = TILE_BYTES / 1024;  // 8, two tokens each
-  constexpr int RING = NSTAGE * TILE_BYTES;
+  constexpr int STEP = 2 * kTile;                  // tokens per step: two tiles
+  constexpr int STEP_BYTES = 2 * TILE_BYTES;
+  constexpr int DMA_PER_STEP = STEP_BYTES / 1024;  // 16 instructions, two tokens each
+  constexpr int DPW = DMA_PER_STEP / WAVES;        // instructions per wave and step
+  constexpr int RING = NSTAGE * STEP_BYTES;
   constexpr int kOPad = D + 4;
-  static_assert(RING >= 16 * kOPad * 4, "output staging reuses the ring");
+  constexpr int STAGE_OUT = 16 * kOPad * 4;        // output staging of one wave
+  constexpr int BUF = RING > WAVES * STAGE_OUT ? RING : WAVES * STAGE_OUT;
+  static_assert(DMA_PER_STEP % WAVES == 0 && kSlotBlock % STEP == 0, "");
 
-  __shared__ __attribute__((aligned(1024))) char smem[RING + kSlotBlock * 4];
-  int32_t* s_slots = (int32_t*)(smem + RING);
+  __shared__ __attribute__((aligned(1024))) char smem[BUF + kSlotBlock * 4];
+  int32_t* s_slots = (int32_t*)(smem + BUF);
   const uint32_t lds_ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
-  const int lane = threadIdx.x;
-  const int lq = lane & 15;  // query position inside the block (column of S^T, row of O)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lq = lane & 15;  // query position inside the wave's 16 (column of S^T, row of O)
   const int lg = lane >> 4;
   const int kvh = blockIdx.y;
   const int G = a.n_q_heads / a.n_kv_heads;
   const int rt0 = blockIdx.z * RT;           // first q head of the group handled here
   const int n_rt = min(RT, G - rt0);         // heads past it compute on zero queries and are not written
 
-  // ---- which (request, block of 16 positions) is this? ----------------------------------
-  const int64_t blk_id = blockIdx.x;
-  if (blk_id >= a.cu_blk[a.batch]) return;
+  // ---- which (request, block of 16 * WAVES positions) is this? ---------------------------
+  // launch order is reversed: a request's last blocks see the most tokens and go first
+  const int64_t n_blocks = a.cu_blk[a.batch];
+  if ((int64_t)blockIdx.x >= n_blocks) return;
+  const int64_t blk_id = n_blocks - 1 - (int64_t)blockIdx.x;
   int lo = 0, hi = a.batch;  // last request with cu_blk[lo] <= blk_id
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
     if (a.cu_blk[mid] <= blk_id) lo = mid; else hi = mid;
   }
   const int i_req = lo;
-  const int q0 = (int)(blk_id - a.cu_blk[i_req]) * 16;
+  const int q0_wg = (int)(blk_id - a.cu_blk[i_req]) * (16 * WAVES);
   const int64_t ext64 = a.extended_lens[i_req];
-  const int n_rows = (int)min((int64_t)16, ext64 - q0);  // >= 1 by construction of cu_blk
+  const int rows_wg = (int)min((int64_t)(16 * WAVES), ext64 - q0_wg);  // >= 1 by construction of cu_blk
+  const int q0 = q0_wg + 16 * wave;
+  const int n_rows = max(0, min(16, rows_wg - 16 * wave));  // 0: this wave only helps to load
   const int64_t q_row0 = a.cu_ext[i_req] + q0;
   int64_t req = a.req_idx[i_req];
   req = req < 0 ? 0 : (req >= a.kv.table_rows ? a.kv.table_rows - 1 : req);
@@ -71,9 +95,10 @@ __global__ __launch_bounds__(64) void prefill_mfma_kernel(PrefillArgs a) {
   const int seq = (int)(seq64 < 0 ? 0 : (seq64 > a.kv.table_cols ? a.kv.table_cols : seq64));
   const int64_t pre64 = a.prefix_lens[i_req];
   const int prefix = (int)(pre64 < 0 ? 0 : (pre64 > seq ? seq : pre64));
-  // row r of the block sees tokens 0 .. prefix + q0 + r; padding columns copy the last real row
-  const int kv_len = min(seq, prefix + q0 + n_rows);
-  const int my_last = min(prefix + q0 + min(lq, n_rows - 1), kv_len - 1);
+  // row r of the request sees tokens 0 .. prefix + r; padding columns copy the wave's last real row
+  const int kv_len = min(seq, prefix + q0_wg + rows_wg);                 // what the workgroup streams
+  const int wave_len = n_rows > 0 ? min(kv_len, prefix + q0 + n_rows) : 0;  // what this wave's rows can see
+  const int my_last = min(prefix + q0 + min(lq, max(n_rows, 1) - 1), kv_len - 1);
   const int32_t* table_row = a.kv.table + req * a.kv.table_row_stride;
   const uint32_t max_slot = (uint32_t)(a.kv.n_slots - 1);
   const uint32_t row_units = (uint32_t)(a.kv.slab_row_stride * 2 / 16);
@@ -121,65 +146,77 @@ __global__ __launch_bounds__(64) void prefill_mfma_kernel(PrefillArgs a) {
 
   for (int blk = 0; blk < kv_len; blk += kSlotBlock) {
     const int n_blk = min(kSlotBlock, kv_len - blk);
-    const int n_tiles = (n_blk + kTile - 1) / kTile;
-    for (int i = lane; i < n_blk; i += 64) {
+    const int n_steps = (n_blk + STEP - 1) / STEP;
+    __syncthreads();  // every wave is done with the previous block's offsets and tiles
+    for (int i = tid; i < n_blk; i += 64 * WAVES) {
       uint32_t s = (uint32_t)table_row[blk + i];
       s = s > max_slot ? max_slot : s;
       s_slots[i] = (int32_t)(s * row_units);
     }
-    // retire every compiler-visible load before the tile loop (see the decode kernel)
+    // retire every compiler-visible load before the step loop (see the decode kernel)
     __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
 
-    auto issue_tile = [&](int tile) {
-      const uint32_t stage = lds_ring + (uint32_t)(tile % NSTAGE) * TILE_BYTES;
-      const uint32_t tok_off = (uint32_t)s_slots[min(tile * kTile + (lane & 15), n_blk - 1)];
+    // a step is loaded by all waves together: wave w issues instructions w*DPW .. w*DPW+DPW-1;
+    // instruction i brings tokens 2i, 2i+1 of the step (tile i / 8); tokens past the end of
+    // the block re-read its last one and are masked below
+    auto issue_step = [&](int step) {
+      const uint32_t stage = lds_ring + (uint32_t)(step % NSTAGE) * STEP_BYTES;
+      const uint32_t tok_off = (uint32_t)s_slots[min(step * STEP + (lane & 31), n_blk - 1)];
 #pragma unroll
-      for (int i = 0; i < DMA_PER_TILE; ++i) {
-        const int t0 = 2 * i;
-        const uint32_t off0 = __builtin_amdgcn_readlane(tok_off, t0);
-        const uint32_t off1 = __builtin_amdgcn_readlane(tok_off, t0 + 1);
+      for (int j = 0; j < DPW; ++j) {
+        const int i = wave * DPW + j;  // wave-uniform
+        const int t0 = 2 * (i & 7);
+        const uint32_t off0 = __builtin_amdgcn_readlane(tok_off, 2 * i);
+        const uint32_t off1 = __builtin_amdgcn_readlane(tok_off, 2 * i + 1);
+        const uint32_t rec = (uint32_t)rec_of_token(t0);
+        const uint32_t xr = (uint32_t)xr_of_rec((int)rec);
         uint64_t src = ((uint64_t)(lane < 32 ? off0 : off1) << 4) + lane_src;
-        src ^= (uint64_t)(xr_of_rec(rec_of_token(t0)) << 4);
-        dma_1k<false>((const void*)src, __builtin_amdgcn_readfirstlane(stage + rec_of_token(t0) * REC));
+        src ^= (uint64_t)(xr << 4);
+        dma_1k<false>((const void*)src,
+                      __builtin_amdgcn_readfirstlane(stage + (uint32_t)(i >> 3) * TILE_BYTES + rec * REC));
       }
     };
 
+    issue_step(0);
+    if (n_steps > 1) issue_step(1);
+
+    for (int step = 0; step < n_steps; ++step) {
+      // this wave's share of the step has landed (one younger step may stay in flight) ...
+      if (step + 1 < n_steps) dma_wait<DPW>(); else dma_wait<0>();
+      // ... and so has everybody's; all waves are also done reading step - 1
+      __syncthreads();
+      if (step + 2 < n_steps) issue_step(step + 2);  // into the stage step - 1 used
+      const char* st = smem + (step % NSTAGE) * STEP_BYTES;
+      const int tok0 = blk + step * STEP + 4 * lg;  // first of this lane's tokens in tile 0; tile 1: + 16
+      if (blk + step * STEP >= wave_len) continue;  // nothing this wave's rows may see (wave-uniform)
+
+      uint4 kf[2][4];
 #pragma unroll
-    for (int t = 0; t < NSTAGE - 1; ++t)
-      if (t < n_tiles) issue_tile(t);
-
-    for (int tile = 0; tile < n_tiles; ++tile) {
-      const int ahead = n_tiles - 1 - tile;
-      if (ahead >= NSTAGE - 1) {
-        issue_tile(tile + NSTAGE - 1);
-        dma_wait<(NSTAGE - 1) * DMA_PER_TILE>();
-      } else if (NSTAGE > 3 && ahead == 2) {
-        dma_wait<2 * DMA_PER_TILE>();
-      } else if (NSTAGE > 2 && ahead == 1) {
-        dma_wait<1 * DMA_PER_TILE>();
-      } else {
-        dma_wait<0>();
-      }
-      const char* st = smem + (tile % NSTAGE) * TILE_BYTES;
-      const int tok0 = blk + tile * kTile + 4 * lg;  // first of this lane's 4 tokens
-
-      uint4 kf[4];
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) kf[s] = *(const uint4*)(st + k_off[s]);
+        for (int s = 0; s < 4; ++s) kf[u][s] = *(const uint4*)(st + u * TILE_BYTES + k_off[s]);
 
-      uint2 pf[RT][PFrag<Tag>::N];
+      uint4 pf[RT][PFrag<Tag>::N];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 sc[2];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) sc = Mma<Tag>::qk(kf[s], qf[rt][s], sc);
-        float sv[4];
+        for (int u = 0; u < 2; ++u) {
+          sc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < 4; ++s) sc[u] = Mma<Tag>::qk(kf[u][s], qf[rt][s], sc[u]);
+        }
+        float sv[8];
         float tmax = kNegInf;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          sv[r] = (tok0 + r <= my_last) ? sc[r] * scale_log2e : kNegInf;  // causal + end of sequence
-          tmax = fmaxf(tmax, sv[r]);
-        }
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            // causal + end of sequence
+            sv[4 * u + r] = (tok0 + 16 * u + r <= my_last) ? sc[u][r] * scale_log2e : kNegInf;
+            tmax = fmaxf(tmax, sv[4 * u + r]);
+          }
         tmax = quad_group_max(tmax);
         if (__any(tmax > m_run[rt])) {
           const float m_new = fmaxf(m_run[rt], tmax);
@@ -195,30 +232,37 @@ __global__ __launch_bounds__(64) void prefill_mfma_kernel(PrefillArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) o_acc[rt][n][r] *= ar[r];
         }
-        float pr[4];
+        float pa[4], pb[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          pr[r] = m_run[rt] == kNegInf ? 0.f : fast_exp2(sv[r] - m_run[rt]);
-          l_run[rt] += pr[r];
+          pa[r] = m_run[rt] == kNegInf ? 0.f : fast_exp2(sv[r] - m_run[rt]);
+          pb[r] = m_run[rt] == kNegInf ? 0.f : fast_exp2(sv[4 + r] - m_run[rt]);
+          l_run[rt] += pa[r] + pb[r];
         }
-        const PFrag<Tag> frag(pr);
+        // k-values 0-3 of the lane: its tokens of tile 0, k-values 4-7: those of tile 1
+        const PFrag<Tag> fa(pa), fb(pb);
 #pragma unroll
-        for (int k = 0; k < PFrag<Tag>::N; ++k) pf[rt][k] = frag.f[k];
+        for (int k = 0; k < PFrag<Tag>::N; ++k) pf[rt][k] = make_uint4(fa.f[k].x, fa.f[k].y, fb.f[k].x, fb.f[k].y);
       }
 #pragma unroll
       for (int n = 0; n < 8; ++n) {
-        const s16x4_t vf = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        const s16x4_t va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (__attribute__((address_space(3))) s16x4_t*)(st + v_off[n]));
+        const s16x4_t vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t*)(st + TILE_BYTES + v_off[n]));
+        const uint2 va2 = __builtin_bit_cast(uint2, va), vb2 = __builtin_bit_cast(uint2, vb);
+        const uint4 vf = make_uint4(va2.x, va2.y, vb2.x, vb2.y);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-          for (int k = 0; k < PFrag<Tag>::N; ++k) o_acc[rt][n] = Mma<Tag>::pv(pf[rt][k], vf, o_acc[rt][n]);
+          for (int k = 0; k < PFrag<Tag>::N; ++k) o_acc[rt][n] = Mma<Tag>::pv32(pf[rt][k], vf, o_acc[rt][n]);
       }
     }
   }
 
   // ---- normalise and write: rows through LDS so that a lane stores 16 contiguous bytes ----
-  float* o_lds = (float*)smem;
+  __syncthreads();  // the ring is free: each wave stages its rows in its own region
+  float* o_lds = (float*)(smem + wave * STAGE_OUT);
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     const float l = quad_group_sum(l_run[rt]);
@@ -245,18 +289,26 @@ template <typename Tag, int RT>
 hipError_t launch_rt(const PrefillArgs& a, hipStream_t stream) {
   const int group = a.n_q_heads / a.n_kv_heads;
   dim3 grid((unsigned)a.max_blocks, a.n_kv_heads, (group + RT - 1) / RT);
-  hipLaunchKernelGGL((prefill_mfma_kernel<Tag, RT, 2>), grid, dim3(64), 0, stream, a);
+  if (a.blk_rows == 64)
+    hipLaunchKernelGGL((prefill_mfma_kernel<Tag, RT, 4>), grid, dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL((prefill_mfma_kernel<Tag, RT, 1>), grid, dim3(64), 0, stream, a);
   return hipGetLastError();
 }
 
 template <typename Tag>
 hipError_t launch_tag(const PrefillArgs& a, hipStream_t stream) {
-  // q heads per workgroup: the whole group up to 4, otherwise two halves
-  switch (a.n_q_heads / a.n_kv_heads) {
+  // q heads per workgroup.  Measured on MI355X (7B chunked prefill, 64-row blocks):
+  // occupancy beats K/V reuse -- 4 heads per workgroup (one wave per SIMD) reach 306
+  // TFLOP/s, 1 head (three waves) 358, 2 heads (two waves) 388, odd groups included.
+  const int g = a.n_q_heads / a.n_kv_heads;
+  int rt = g == 1 ? 1 : 2;
+  const char* e = getenv("BSGL_PREFILL_RT");  // tuning override
+  if (e != nullptr && *e != '\0') rt = atoi(e);
+  switch (rt) {
     case 1: return launch_rt<Tag, 1>(a, stream);
     case 2: return launch_rt<Tag, 2>(a, stream);
-    case 3: case 5: case 6: return launch_rt<Tag, 3>(a, stream);
-    case 4: case 7: case 8: return launch_rt<Tag, 4>(a, stream);
+    case 4: return launch_rt<Tag, 4>(a, stream);
     default: return hipErrorInvalidValue;
   }
 }

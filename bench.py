@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--layers", type=int, default=28)
     ap.add_argument("--max-context", type=int, default=4096)
-    ap.add_argument("--table", choices=["perm", "contig"], default="perm")
+    ap.add_argument("--table", choices=["perm", "contig", "radix", "ragged"], default="perm")
     ap.add_argument("--kv-layout", choices=["interleaved", "split"], default="interleaved")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 generic, 2 matrix-core decode kernel")
     ap.add_argument("--splits", type=int, default=0, help="sequence splits (0 = library heuristic)")
@@ -90,6 +90,21 @@ class Workload:
         t = torch.zeros((B, args.max_context), dtype=torch.int32, device=dev)
         t[:, :s_loc] = (torch.arange(B * s_loc, device=dev, dtype=torch.int32) + 1).view(B, s_loc)
         self.tables["contig"] = t
+        # radix-cache reuse: groups of 8 requests share the slots of their first half
+        # (a common prompt prefix held once by the radix tree, radix_cache.py:142-205)
+        t = self.tables["perm"].clone()
+        half = s_loc // 2
+        for g0 in range(0, B, 8):
+            t[g0 : g0 + 8, :half] = t[g0, :half]
+        self.tables["radix"] = t
+        # ragged batch: lengths uniform in [S/2, 3S/2) with the same total work on average
+        self.ragged_seq = torch.randint(max(1, S // 2), 3 * S // 2, (B,), generator=gen, device=dev, dtype=torch.int64)
+        self.ragged_seq = layout.local_len(self.ragged_seq.clamp_max(args.max_context))
+        t = torch.zeros((B, args.max_context), dtype=torch.int32, device=dev)
+        n_r = int(self.ragged_seq.max().item())
+        t[:, :n_r] = (torch.randperm(B * n_r, generator=gen, device=dev).to(torch.int32) % size + 1).view(B, n_r)
+        self.tables["ragged"] = t
+        self.uniform_seq = self.local_seq
         self.q = torch.randn((L, B, self.hq_l, self.dim), generator=gen, device=dev).to(self.dtype)
         self.k = torch.randn((L, B, self.hkv_l, self.dim), generator=gen, device=dev).to(self.dtype)
         # v as the model hands it over: a column slice of a wider projection row
@@ -108,6 +123,7 @@ class Workload:
 
     def set_table(self, kind):
         self.r2t.req_to_token.copy_(self.tables[kind])
+        self.local_seq = self.ragged_seq if kind == "ragged" else self.uniform_seq
         # slot of the token written this step = last local position of each request
         self.loc = self.r2t.req_to_token[self.req, (self.local_seq - 1).clamp_min(0)].contiguous()
         self.fb = self.pkg.SimplifiedForwardBatch.create_decode_batch(
@@ -372,11 +388,16 @@ def main():
         r2 = make_runner(wl, other, tp_group)
         extras[f"{other}_ms_per_step"] = timed_steps(r2, args.steps, args.warmup, 1) / args.steps * 1e3
         extras["backend_forward_eager_ms_per_step"] = timed_steps(wl.backend_step, args.steps, args.warmup, 1) / args.steps * 1e3
-        alt = "contig" if args.table == "perm" else "perm"
-        wl.set_table(alt)
-        r3 = make_runner(wl, args.mode, tp_group)
-        extras[f"{alt}_table_ms_per_step"] = timed_steps(r3, args.steps, args.warmup, 1) / args.steps * 1e3
-        extras[f"{alt}_table_launch_us"] = kernel_event_times(wl, 5) * 1e3
+        for alt in ("contig", "radix", "ragged", "perm"):
+            if alt == args.table:
+                continue
+            wl.set_table(alt)
+            r3 = make_runner(wl, args.mode, tp_group)
+            ms = timed_steps(r3, args.steps, args.warmup, 1) / args.steps * 1e3
+            extras[f"{alt}_table_ms_per_step"] = ms
+            extras[f"{alt}_table_tokens_per_s"] = args.batch / ms * 1e3
+            if alt == "ragged":
+                extras["ragged_mean_seq"] = float(wl.local_seq.float().mean().item())
         wl.set_table(args.table)
         result["extras"] = extras
 

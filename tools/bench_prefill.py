@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Extend (prefill) attention timing on one GPU: Qwen2.5-7B shapes by default
+(28 q heads, 4 kv heads, head_dim 128, bf16), batch of requests each extending
+`--ext` tokens over a cached prefix of `--prefix` tokens (a chunk of a chunked
+prefill is exactly that).  Reports ms per layer call and TFLOP/s with
+flops = 4 * Hq * D * (ext * prefix + ext * (ext + 1) / 2) per request."""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--ext", type=int, default=512)
+    ap.add_argument("--prefix", type=int, default=1536)
+    ap.add_argument("--hq", type=int, default=28)
+    ap.add_argument("--hkv", type=int, default=4)
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--table", default="perm")
+    a = ap.parse_args()
+    import baby_sglang_amd as pkg
+
+    dev = torch.device("cuda:0")
+    dim, dtype = 128, torch.bfloat16
+    seq = a.prefix + a.ext
+    size = a.batch * seq
+    gen = torch.Generator(device=dev).manual_seed(0)
+    kv = pkg.MHATokenToKVPool(size, dtype, a.hkv, dim, 1, "cuda:0")
+    kv.arena.normal_(generator=gen)
+    r2t = pkg.ReqToTokenPool(a.batch, seq, "cuda:0")
+    if a.table == "perm":
+        slots = torch.randperm(size, generator=gen, device=dev).to(torch.int32) + 1
+    else:
+        slots = torch.arange(size, device=dev, dtype=torch.int32) + 1
+    r2t.req_to_token.copy_(slots.view(a.batch, seq))
+    q = torch.randn((a.batch * a.ext, a.hq, dim), generator=gen, device=dev).to(dtype)
+    rows = torch.arange(a.batch, device=dev)
+    seq_t = torch.full((a.batch,), seq, dtype=torch.int64, device=dev)
+    pre_t = torch.full((a.batch,), a.prefix, dtype=torch.int64, device=dev)
+    ext_t = seq_t - pre_t
+    k_slab, v_slab = kv.get_kv_buffer(0)
+    ws = torch.empty(pkg._hip.prefill_workspace_bytes(a.batch, q.shape[0], a.hq, dim), dtype=torch.uint8, device=dev)
+    out = torch.empty((q.shape[0], a.hq * dim), dtype=dtype, device=dev)
+
+    def call():
+        return pkg._hip.paged_prefill(q, k_slab, v_slab, r2t.req_to_token, rows, seq_t, pre_t, ext_t,
+                                      variant=a.variant, out=out, workspace=ws)
+
+    call()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.reps):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / a.reps
+    flops = 4.0 * a.hq * dim * (a.ext * a.prefix + a.ext * (a.ext + 1) / 2) * a.batch
+    kv_bytes = a.batch * seq * a.hkv * dim * 2 * 2
+    print(f"batch={a.batch} ext={a.ext} prefix={a.prefix} Hq={a.hq} Hkv={a.hkv} variant={a.variant} table={a.table}: "
+          f"{ms:.3f} ms/layer  {flops / ms / 1e9:.1f} TFLOP/s  (KV of the batch {kv_bytes / 1e6:.0f} MB, "
+          f"{a.batch * a.ext / ms * 1e3:.0f} extend tokens/s/layer)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
