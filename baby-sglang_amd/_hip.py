@@ -31,6 +31,7 @@ BSGL_ERR_WORKSPACE = -4
 
 DECODE_AUTO, DECODE_VALU, DECODE_MFMA = 0, 1, 2
 DECODE_FUSE_KV_WRITE = 0x100  # caller asserts: out_cache_loc slots belong to their own request only
+DECODE_UNIFORM_SPLITS = 0x200  # exactly n_splits equal pieces per request instead of length-balanced ones
 
 _DTYPE_CODE = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
 
@@ -45,6 +46,7 @@ _vp, _i64, _i32, _f32, _sz = (
 SIGNATURES = {
     "bsgl_abi_version": (ctypes.c_int, []),
     "bsgl_last_error": (ctypes.c_char_p, []),
+    "bsgl_debug_decode_trace": (None, [_vp]),
     "bsgl_kv_scatter": (
         ctypes.c_int,
         [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp],
@@ -198,6 +200,7 @@ def paged_decode(
     v_new: Optional[torch.Tensor] = None,
     out_cache_loc: Optional[torch.Tensor] = None,
     fuse_kv_write: bool = False,
+    uniform_splits: bool = False,
 ) -> torch.Tensor:
     """softmax(q K^T * scale) V over page-table rows; returns [B, Hq * D].
 
@@ -208,6 +211,9 @@ def paged_decode(
     decode kernel, which is only valid when each slot in ``out_cache_loc`` is
     referenced by its own request's page-table row alone.  A caller-provided
     ``workspace`` must have been created zero-filled (``new_decode_workspace``).
+    ``n_splits`` bounds the pieces a request's sequence is cut into; pieces have
+    one batch-wide length unless ``uniform_splits`` asks for exactly ``n_splits``
+    equal pieces per request.
     """
     _need_gpu(q, k_slab, v_slab, req_to_token, req_pool_indices, seq_lens)
     q = _rows(q)
@@ -236,6 +242,8 @@ def paged_decode(
     need = decode_workspace_bytes(batch, hq, dim, n_splits, out_dtype != q.dtype)
     if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
         workspace = torch.zeros(need, dtype=torch.uint8, device=q.device)
+    if uniform_splits:
+        variant |= DECODE_UNIFORM_SPLITS
     new = (None, None, 0, 0, None)
     if k_new is not None or v_new is not None or out_cache_loc is not None:
         if k_new is None or v_new is None or out_cache_loc is None:

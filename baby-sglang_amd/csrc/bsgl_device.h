@@ -132,6 +132,35 @@ template <int LANES> __device__ __forceinline__ float group_max(float x) {
   return x;
 }
 
+// Inclusive scan over the 64 lanes of a wave on the vector ALU (no LDS traffic): three
+// shifted adds give windows of 4, row_shr:4 / row_shr:8 complete each 16-lane row,
+// row_bcast:15 / row_bcast:31 carry the totals of rows 0 and 2 / of lanes 0-31 upward.
+// DPP controls: row_shr:n = 0x110 + n, row_bcast:15 = 0x142, row_bcast:31 = 0x143; a
+// lane switched off by the row / bank mask, or shifted in from outside, contributes
+// the identity.  Lane 63 ends up with the wave's total.
+struct ScanAdd {
+  static constexpr int kIdentity = 0;
+  __device__ static __forceinline__ int op(int a, int b) { return a + b; }
+};
+struct ScanMax {
+  static constexpr int kIdentity = 0;  // for non-negative inputs
+  __device__ static __forceinline__ int op(int a, int b) { return a > b ? a : b; }
+};
+template <typename Op, int CTRL, int ROW_MASK, int BANK_MASK> __device__ __forceinline__ int scan_step(int x) {
+  return Op::op(x, __builtin_amdgcn_update_dpp(Op::kIdentity, x, CTRL, ROW_MASK, BANK_MASK, false));
+}
+template <typename Op> __device__ __forceinline__ int wave_inclusive_scan(int x) {
+  const int s1 = __builtin_amdgcn_update_dpp(Op::kIdentity, x, 0x111, 0xf, 0xf, false);
+  const int s2 = __builtin_amdgcn_update_dpp(Op::kIdentity, x, 0x112, 0xf, 0xf, false);
+  const int s3 = __builtin_amdgcn_update_dpp(Op::kIdentity, x, 0x113, 0xf, 0xf, false);
+  int y = Op::op(Op::op(x, s1), Op::op(s2, s3));
+  y = scan_step<Op, 0x114, 0xf, 0xe>(y);
+  y = scan_step<Op, 0x118, 0xf, 0xc>(y);
+  y = scan_step<Op, 0x142, 0xa, 0xf>(y);
+  y = scan_step<Op, 0x143, 0xc, 0xf>(y);
+  return y;
+}
+
 constexpr float kNegInf = -__builtin_huge_valf();
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;

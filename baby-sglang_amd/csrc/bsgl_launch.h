@@ -46,12 +46,21 @@ struct DecodeArgs {
   float* ws_o;    // [n_splits, rows * n_q_heads, head_dim]   (unless direct)
   float* ws_lse;  // [n_splits, rows * n_q_heads]
   uint32_t* counters;  // [rows, head groups] tickets of the in-kernel merge; zero between launches; may be NULL
+  // > 0: splits are cut by LENGTH, not by count: every row is cut into pieces of one
+  // batch-wide size chosen so that the batch yields about rows * balance_target pieces
+  // (and no row more than n_splits); needs the in-kernel merge.  0: n_splits equal
+  // pieces per row.
+  int32_t balance_target;
   // fused KV write of the new token of each row (decode only); new_loc == NULL disables it
   const void* k_new;
   const void* v_new;
   int64_t k_new_stride;
   int64_t v_new_stride;
   const int32_t* new_loc;
+  // tuning aid, normally NULL: 8 x uint64 per workgroup (in launch order): start, after
+  // the prologue, after the streaming loop, end (100 MHz ticks), XCC id, HW id, row, piece
+  uint64_t* trace;
+  int32_t trace_flags;
 };
 
 struct MergeArgs {
@@ -128,6 +137,9 @@ hipError_t launch_decode_valu(const DecodeArgs& a, hipStream_t stream);
 
 bool decode_mfma_supported(const DecodeArgs& a, const char** why);
 hipError_t launch_decode_mfma(const DecodeArgs& a, hipStream_t stream);
+// tuning aid: device buffer that the matrix-core decode kernel writes per-workgroup
+// timestamps into (NULL switches it off); process-wide, not thread safe
+void set_decode_trace(uint64_t* buf);
 
 hipError_t launch_merge(const MergeArgs& a, hipStream_t stream);
 hipError_t launch_kv_scatter(const ScatterArgs& a, hipStream_t stream);

@@ -77,6 +77,7 @@ int run_decode(bsgl::DecodeArgs& a, int32_t variant, uint32_t* counters, hipStre
   const char* why = "";
   bool use_mfma = false;
   const bool may_fuse_kv = (variant & BSGL_DECODE_FUSE_KV_WRITE) != 0;
+  const bool uniform_splits = (variant & BSGL_DECODE_UNIFORM_SPLITS) != 0;
   variant &= 0xff;
   if (variant == BSGL_DECODE_MFMA) {
     if (!bsgl::decode_mfma_supported(a, &why)) return fail(BSGL_ERR_UNSUPPORTED, "MFMA decode: %s", why);
@@ -116,6 +117,11 @@ int run_decode(bsgl::DecodeArgs& a, int32_t variant, uint32_t* counters, hipStre
   const bool tickets_fit = (size_t)a.rows * (size_t)a.n_kv_heads * 4 <= kCounterBytes &&
                            (size_t)a.n_splits * a.rows * a.n_q_heads * a.head_dim * 4 < (1ull << 31);
   a.counters = (use_mfma && tickets_fit && env_int("BSGL_NO_FUSED_MERGE", 0) == 0) ? counters : nullptr;
+  // length-balanced pieces: needs the in-kernel merge (a row's piece count varies) and a
+  // batch small enough for every workgroup to scan its seq_lens
+  a.balance_target = 0;
+  if (a.counters != nullptr && a.n_splits > 1 && a.rows <= 1024 && a.kv.table_cols <= (1 << 20) && !uniform_splits && env_int("BSGL_DECODE_BALANCE", 1) != 0)
+    a.balance_target = (a.n_splits + 1) / 2;
   const hipError_t e = use_mfma ? bsgl::launch_decode_mfma(a, stream) : bsgl::launch_decode_valu(a, stream);
   if (e != hipSuccess) return hip_fail("decode launch", e);
   return BSGL_OK;
@@ -126,6 +132,8 @@ int run_decode(bsgl::DecodeArgs& a, int32_t variant, uint32_t* counters, hipStre
 extern "C" {
 
 int bsgl_abi_version(void) { return 1; }
+
+void bsgl_debug_decode_trace(void* device_buf) { bsgl::set_decode_trace((uint64_t*)device_buf); }
 
 const char* bsgl_last_error(void) { return g_err; }
 
@@ -167,7 +175,9 @@ int bsgl_kv_scatter(void* k_slab, void* v_slab, int64_t slab_row_stride, int64_t
   return BSGL_OK;
 }
 
-int32_t bsgl_decode_num_splits(int32_t batch, int32_t n_kv_heads, int32_t max_context_len) {
+// pieces per request that fill the machine when every request has the same length;
+// depth_factor 2 leaves room for requests of twice the mean length
+static int32_t decode_splits(int32_t batch, int32_t n_kv_heads, int32_t max_context_len, int depth_factor) {
   if (batch <= 0) return 1;
   if (n_kv_heads < 1) n_kv_heads = 1;
   // enough workgroups to put several on each of the 256 CUs, but no split
@@ -177,11 +187,18 @@ int32_t bsgl_decode_num_splits(int32_t batch, int32_t n_kv_heads, int32_t max_co
   // one workgroup per (request, kv head, split)
   const int64_t per_split = (int64_t)batch * n_kv_heads;
   int splits = (int)((target_wgs + per_split - 1) / per_split);
+  // twice that as grid depth: with length-balanced pieces a request of twice the
+  // batch's mean length is cut into twice the mean number of pieces
+  if (splits > 1) splits *= depth_factor;
   const int by_len = max_context_len > 0 ? (max_context_len + min_chunk - 1) / min_chunk : 1;
   if (splits > by_len) splits = by_len;
   if (splits > 64) splits = 64;
   if (splits < 1) splits = 1;
   return splits;
+}
+
+int32_t bsgl_decode_num_splits(int32_t batch, int32_t n_kv_heads, int32_t max_context_len) {
+  return decode_splits(batch, n_kv_heads, max_context_len, 2);
 }
 
 size_t bsgl_decode_counter_bytes(void) { return kCounterBytes; }
@@ -256,7 +273,7 @@ int bsgl_paged_decode(void* out, int64_t out_row_stride, float* lse, const void*
 }
 
 static int32_t prefill_row_splits(int32_t total_q_tokens, int32_t max_context_len) {
-  return bsgl_decode_num_splits(total_q_tokens, 1, max_context_len);
+  return decode_splits(total_q_tokens, 1, max_context_len, 1);  // equal pieces per row (generic kernel)
 }
 
 

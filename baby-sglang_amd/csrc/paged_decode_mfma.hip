@@ -31,13 +31,26 @@
 // slot equals the row's new slot reads the NEW rows instead of the slab, so the
 // write needs no earlier kernel and no ordering against the gather.
 //
+// Balanced splits (with the fused merge): pieces have one batch-wide target length
+// -- about sum(seq_lens) / (rows * target) tokens, and at least max(seq_lens) /
+// n_splits -- so a long request is cut into more pieces than a short one and every
+// workgroup streams about the same bytes.  The grid is FLAT: workgroup b is piece
+// b / head_groups of the batch's piece list, which each workgroup rebuilds for
+// itself from seq_lens (sum, max, running piece counts: no host read, no extra
+// launch).  Consecutive workgroups are therefore all live -- idle workgroups
+// scattered through a launch make the hardware's round-robin placement pile the
+// live ones onto a subset of the CUs, which costs up to 50 % on ragged batches --
+// and only the few past the end of the list leave at once.
+//
 // Fused merge (when the sequence is split): a workgroup stores its normalised
 // partial output and log-sum-exp write-through (sc1, 16 bytes per lane via an
 // LDS transpose), drains its stores, then draws a ticket with one agent-scope
 // atomic add on the (row, head group) counter.  The workgroup that draws the
 // last ticket reads every partial back with sc1 loads (they bypass its L1),
 // merges them and writes the final rows, then stores 0 to the counter: counters
-// are zero before and after every launch.
+// are zero before and after every launch.  (Drawing the ticket early and letting
+// the last drawer wait for a "ready" count was measured and is slower: under
+// load every trip to memory costs about 2.3 us, and the wait adds trips.)
 #include "bsgl_device.h"
 #include "bsgl_launch.h"
 #include "bsgl_mfma.h"
@@ -48,8 +61,11 @@ namespace {
 
 using namespace mfma;
 
+// Two waves per SIMD (8 single-wave workgroups per CU, which is also what the LDS rings
+// allow): 256 registers per lane, which bounds how many partial rows the merge reads at once.
 template <typename Tag, int HPT, int NSTAGE, bool NT>
-__global__ __launch_bounds__(64) void decode_mfma_kernel(DecodeArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
+void decode_mfma_kernel(DecodeArgs a) {
   using E = Elem<Tag>;
   constexpr int D = 128;
   constexpr int REC = HPT * 512;                // bytes of one token record in LDS
@@ -65,22 +81,94 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(DecodeArgs a) {
   const uint32_t lds_ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
   const int lane = threadIdx.x;
-  const int row = blockIdx.x;
-  const int head0 = blockIdx.y * HPT;
-  const int split = blockIdx.z;
+  uint64_t* trace = nullptr;
+  if (a.trace != nullptr) {
+    trace = a.trace + 8 * ((uint64_t)blockIdx.x + (uint64_t)gridDim.x * (blockIdx.y + (uint64_t)gridDim.y * blockIdx.z));
+    uint32_t xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    if (lane == 0) {
+      trace[0] = wall_clock64();
+      trace[1] = trace[2] = trace[3] = 0;
+      trace[4] = xcc;
+      trace[5] = hw;
+      trace[6] = trace[7] = ~0ull;
+    }
+  }
+  const int n_hg = a.n_kv_heads / HPT;  // head groups
+  int row = blockIdx.x, hg = blockIdx.y, split = blockIdx.z, n_parts = a.n_splits;
+  int flat_req = -1, flat_seq = 0;  // the row's page-table row and length, when found by the flat search
+  if (a.balance_target > 0) {
+    // ---- flat grid: which (row, piece) is this? -------------------------------------
+    const unsigned piece_cap = gridDim.x / (unsigned)n_hg;
+    const bool hg_major = a.trace_flags & 1;
+    hg = hg_major ? (int)(blockIdx.x / piece_cap) : (int)(blockIdx.x % (unsigned)n_hg);
+    const int piece = hg_major ? (int)(blockIdx.x % piece_cap) : (int)(blockIdx.x / (unsigned)n_hg);
+    // per-lane request data, 64 rows at a time; the first block is loaded once for both passes
+    auto len_of = [&](int i) {
+      const int64_t s64 = i < a.rows ? a.seq_lens[i] : 0;
+      const int64_t cap = a.kv.table_cols < (1 << 20) ? a.kv.table_cols : (1 << 20);
+      return (int)(s64 < 0 ? 0 : (s64 > cap ? cap : s64));
+    };
+    auto req_of = [&](int i) {
+      const int64_t r64 = i < a.rows ? a.req_idx[i] : 0;
+      return (int)(r64 < 0 ? 0 : (r64 >= a.kv.table_rows ? a.kv.table_rows - 1 : r64));
+    };
+    const int len0 = len_of(lane);
+    const int req0 = req_of(lane);
+    int tot = 0, longest = 0;
+    for (int r0 = 0; r0 < a.rows; r0 += 64) {
+      const int s = r0 == 0 ? len0 : len_of(r0 + lane);
+      tot += __builtin_amdgcn_readlane(wave_inclusive_scan<ScanAdd>(s), 63);
+      longest = max(longest, __builtin_amdgcn_readlane(wave_inclusive_scan<ScanMax>(s), 63));
+    }
+    const int want = a.rows * a.balance_target;
+    int piece_len = max((tot + want - 1) / want, (longest + a.n_splits - 1) / a.n_splits);
+    piece_len = max(kTile, (piece_len + kTile - 1) / kTile * kTile);
+    int base = 0;
+    row = -1;
+    for (int r0 = 0; r0 < a.rows; r0 += 64) {
+      const int s = r0 == 0 ? len0 : len_of(r0 + lane);
+      const int parts = r0 + lane < a.rows ? min(a.n_splits, max(1, (s + piece_len - 1) / piece_len)) : 0;
+      const int incl = wave_inclusive_scan<ScanAdd>(parts);
+      const int blk_total = __builtin_amdgcn_readlane(incl, 63);
+      if (piece < base + blk_total) {
+        const int excl = base + incl - parts;
+        const unsigned long long hit = __ballot(piece >= excl && piece < excl + parts);  // one lane: parts >= 1
+        const int src = __ffsll((long long)hit) - 1;
+        row = r0 + src;
+        split = piece - __builtin_amdgcn_readlane(excl, src);
+        n_parts = __builtin_amdgcn_readlane(parts, src);
+        flat_seq = __builtin_amdgcn_readlane(s, src);
+        flat_req = __builtin_amdgcn_readlane(r0 == 0 ? req0 : req_of(r0 + lane), src);
+        break;
+      }
+      base += blk_total;
+    }
+    if (row < 0) return;  // past the batch's last piece
+  }
+  const int head0 = hg * HPT;
   const int G = a.n_q_heads / a.n_kv_heads;
   const int lq = lane & 15;   // q head (column of S^T / row of O) or d column
   const int lg = lane >> 4;   // lane group
 
   // ---- this row's token range (multiples of the tile so splits start on tiles) ----
-  int64_t req = a.req_idx[row];
-  req = req < 0 ? 0 : (req >= a.kv.table_rows ? a.kv.table_rows - 1 : req);
-  const int64_t seq64 = a.seq_lens[row];
-  const int seq = (int)(seq64 < 0 ? 0 : (seq64 > a.kv.table_cols ? a.kv.table_cols : seq64));
-  int chunk = (seq + a.n_splits - 1) / a.n_splits;
+  int64_t req;
+  int seq;
+  if (a.balance_target > 0) {
+    req = flat_req;
+    seq = flat_seq;
+  } else {
+    req = a.req_idx[row];
+    req = req < 0 ? 0 : (req >= a.kv.table_rows ? a.kv.table_rows - 1 : req);
+    const int64_t seq64 = a.seq_lens[row];
+    seq = (int)(seq64 < 0 ? 0 : (seq64 > a.kv.table_cols ? a.kv.table_cols : seq64));
+  }
+  // the row's pieces are equal among themselves (a piece past the end is empty)
+  int chunk = (seq + n_parts - 1) / n_parts;
   chunk = (chunk + kTile - 1) / kTile * kTile;
   const int start = split * chunk;
-  const int end = min(seq, start + chunk);
+  const int end = (split == n_parts - 1) ? seq : min(seq, start + chunk);
   const int32_t* table_row = a.kv.table + req * a.kv.table_row_stride;
   const uint32_t max_slot = (uint32_t)(a.kv.n_slots - 1);
   const uint32_t row_units = (uint32_t)(a.kv.slab_row_stride * 2 / 16);
@@ -146,6 +234,11 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(DecodeArgs a) {
   for (int n = 0; n < 8; ++n)
     v_off[n] = v_rec * REC + HPT * 256 + (((2 * n + ((lane >> 1) & 1)) ^ xr_of_rec(v_rec)) << 4) + ((lane & 1) << 3);
 
+  if (trace != nullptr && lane == 0) {
+    trace[1] = wall_clock64();
+    trace[6] = (uint64_t)row | ((uint64_t)hg << 32);
+    trace[7] = (uint64_t)split | ((uint64_t)n_parts << 32);
+  }
   float m_run[HPT], l_run[HPT];
   f32x4 o_acc[HPT][8];
 #pragma unroll
@@ -156,6 +249,8 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(DecodeArgs a) {
     for (int n = 0; n < 8; ++n) o_acc[hh][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
+  const bool direct = n_parts == 1 && a.out_dtype == a.dtype;
+  const bool fused_merge = !direct && a.counters != nullptr;
   for (int blk = start; blk < end; blk += kSlotBlock) {
     const int n_blk = min(kSlotBlock, end - blk);
     const int n_tiles = (n_blk + kTile - 1) / kTile;
@@ -259,16 +354,15 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(DecodeArgs a) {
     }
   }
 
+  if (trace != nullptr && lane == 0) trace[2] = wall_clock64();
   // ---- finish: sum l over the lane groups, normalise, write ---------------------------
-  const bool direct = a.n_splits == 1 && a.out_dtype == a.dtype;
-  const bool fused_merge = !direct && a.counters != nullptr;
   const int64_t n_rh = (int64_t)a.rows * a.n_q_heads;
-  float* o_lds = (float*)smem;          // the ring is idle now: [16 q][kOPad] floats per head
   constexpr int kOPad = D + 4;
   const auto ws_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ws_o + ((int64_t)split * n_rh + (int64_t)row * a.n_q_heads) * D), 0,
                                                          (int)(a.n_q_heads * D * 4), 0x00020000);
 #pragma unroll
   for (int hh = 0; hh < HPT; ++hh) {
+    float* o_lds = (float*)smem;  // the ring is idle now: [16 q][kOPad] floats
     const float l = quad_group_sum(l_run[hh]);
     const float inv = l > 0.f ? 1.f / l : 0.f;
     const float lse = l > 0.f ? (m_run[hh] + __builtin_amdgcn_logf(l)) * kLn2 : kNegInf;
@@ -289,16 +383,16 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(DecodeArgs a) {
       }
       continue;
     }
-    // partial state: rows through LDS so that every lane stores 16 contiguous bytes
+    // partial state: rows through LDS so that every lane stores (or later reads) whole rows
+#pragma unroll
+    for (int n = 0; n < 8; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o_lds[(4 * lg + r) * kOPad + 16 * n + lq] = o_acc[hh][n][r] * ir[r];
     if (lg == 0 && lq < G) {
       float* pl = a.ws_lse + (int64_t)split * n_rh + (int64_t)row * a.n_q_heads + hq0 + lq;
       if (fused_merge) __hip_atomic_store(pl, lse, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else *pl = lse;
     }
-#pragma unroll
-    for (int n = 0; n < 8; ++n)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o_lds[(4 * lg + r) * kOPad + 16 * n + lq] = o_acc[hh][n][r] * ir[r];
     for (int idx = lane; idx < G * (D / 4); idx += 64) {
       const int q = idx / (D / 4), c4 = idx % (D / 4);
       const f32x4 v = *(const f32x4*)(o_lds + q * kOPad + c4 * 4);
@@ -308,62 +402,69 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(DecodeArgs a) {
       else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ws_rsrc, off, 0, 0);
     }
   }
-  if (!fused_merge) return;
-
+  if (!fused_merge) {
+    if (trace != nullptr && lane == 0) trace[3] = wall_clock64();
+    return;
+  }
   // ---- ticket: the last workgroup of this (row, head group) merges all splits ----------
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every partial byte of this wave has left
-  uint32_t* counter = a.counters + (int64_t)row * gridDim.y + blockIdx.y;
+  uint32_t* counter = a.counters + (int64_t)row * n_hg + hg;
   uint32_t ticket = 0;
   if (lane == 0) ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   ticket = __builtin_amdgcn_readfirstlane(ticket);
-  if (ticket != (uint32_t)a.n_splits - 1) return;
+  if (ticket != (uint32_t)n_parts - 1) {
+    if (trace != nullptr && lane == 0) trace[3] = wall_clock64();
+    return;
+  }
 
   // All partial bytes were stored sc1 and drained before their tickets; read them
   // back with sc1 loads only (aux 16), which bypass this CU's vector cache.
-  // Lane p owns part p's weight (n_splits <= 64); loads of up to 8 heads x 8 parts
+  // Lane p owns part p's weight (n_splits <= 64); loads of up to 6 heads x 8 parts
   // are issued together so the merge costs two memory round trips, not one per head.
-  const int n_parts = a.n_splits;
   const int nh = HPT * G;
   const int64_t rh0 = (int64_t)row * a.n_q_heads + (int64_t)head0 * G;
   const auto lse_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ws_lse + rh0), 0, (int)(((int64_t)(n_parts - 1) * n_rh + nh) * 4), 0x00020000);
   const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ws_o + rh0 * D), 0, (int)((((int64_t)(n_parts - 1) * n_rh + nh) * D) * 4), 0x00020000);
   const int part_lse_stride = (int)(n_rh * 4);
   const int part_o_stride = (int)(n_rh * D * 4);
-  for (int h0 = 0; h0 < nh; h0 += 8) {
-    float my_lse[8];
+  constexpr int kMH = 6;  // heads per round (the GQA group of the 1.5B model in one round)
+  constexpr int kMP = 8;  // parts per round; kMH * kMP * 2 registers hold a round's partial rows
+  for (int h0 = 0; h0 < nh; h0 += kMH) {
+    float my_lse[kMH];
+    // (unconditional loads, clamped to a real part: they all leave together)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < kMH; ++j) {
       const int h = min(h0 + j, nh - 1);
-      my_lse[j] = lane < n_parts
-          ? as_f32(__builtin_amdgcn_raw_buffer_load_b32(lse_rsrc, lane * part_lse_stride + h * 4, 0, 16)) : kNegInf;
+      my_lse[j] = as_f32(__builtin_amdgcn_raw_buffer_load_b32(lse_rsrc, min(lane, n_parts - 1) * part_lse_stride + h * 4, 0, 16));
     }
-    float acc[8][2];
-    float my_w[8], mx[8], wsum[8];
+    float acc[kMH][2];
+    float my_w[kMH], mx[kMH], wsum[kMH];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j][0] = acc[j][1] = 0.f;
-    for (int p0 = 0; p0 < n_parts; p0 += 8) {
-      u32x2_t v[8][8];
+    for (int j = 0; j < kMH; ++j) acc[j][0] = acc[j][1] = 0.f;
+    for (int p0 = 0; p0 < n_parts; p0 += kMP) {
+      u32x2_t v[kMH][kMP];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < kMH; ++j) {
         const int h = min(h0 + j, nh - 1);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < kMP; ++i) {
           const int p = min(p0 + i, n_parts - 1);
           v[j][i] = __builtin_amdgcn_raw_buffer_load_b64(o_rsrc, p * part_o_stride + (h * D + lane * 2) * 4, 0, 16);
         }
       }
-      if (p0 == 0) {
+      if (p0 == 0) {  // (first use of the lse loads: after the partial rows have been requested)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < kMH; ++j) {
+          my_lse[j] = lane < n_parts ? my_lse[j] : kNegInf;
           mx[j] = group_max<64>(my_lse[j]);
           my_w[j] = (my_lse[j] == kNegInf) ? 0.f : fast_exp2((my_lse[j] - mx[j]) * kLog2e);
           wsum[j] = group_sum<64>(my_w[j]);
         }
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < kMH; ++j) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < kMP; ++i) {
           const float w = p0 + i < n_parts ? __shfl(my_w[j], min(p0 + i, n_parts - 1)) : 0.f;
           acc[j][0] = fmaf(w, as_f32(v[j][i].x), acc[j][0]);
           acc[j][1] = fmaf(w, as_f32(v[j][i].y), acc[j][1]);
@@ -371,7 +472,7 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(DecodeArgs a) {
       }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < kMH; ++j) {
       if (h0 + j >= nh) break;
       const float inv = wsum[j] > 0.f ? 1.f / wsum[j] : 0.f;
       const int64_t hq = (int64_t)head0 * G + h0 + j;
@@ -385,7 +486,10 @@ __global__ __launch_bounds__(64) void decode_mfma_kernel(DecodeArgs a) {
     }
   }
   if (lane == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (trace != nullptr && lane == 0) trace[3] = wall_clock64() | (1ull << 63);  // top bit: this one merged
 }
+
+uint64_t* g_trace = nullptr;
 
 int env_int(const char* name, int dflt) {
   const char* s = getenv(name);
@@ -395,6 +499,8 @@ int env_int(const char* name, int dflt) {
 template <typename Tag, int HPT, int NSTAGE>
 hipError_t launch_inst(const DecodeArgs& a, hipStream_t stream) {
   dim3 grid(a.rows, a.n_kv_heads / HPT, a.n_splits);
+  // flat list of length-balanced pieces: at most rows * target + rows of them
+  if (a.balance_target > 0) grid = dim3((unsigned)((int64_t)a.rows * (a.balance_target + 1) * (a.n_kv_heads / HPT)), 1, 1);
   if (env_int("BSGL_MFMA_NT", 1))
     hipLaunchKernelGGL((decode_mfma_kernel<Tag, HPT, NSTAGE, true>), grid, dim3(64), 0, stream, a);
   else
@@ -443,8 +549,13 @@ bool decode_mfma_supported(const DecodeArgs& a, const char** why) {
   return true;
 }
 
-hipError_t launch_decode_mfma(const DecodeArgs& a, hipStream_t stream) {
-  if (a.rows == 0) return hipSuccess;
+void set_decode_trace(uint64_t* buf) { g_trace = buf; }
+
+hipError_t launch_decode_mfma(const DecodeArgs& a_in, hipStream_t stream) {
+  if (a_in.rows == 0) return hipSuccess;
+  DecodeArgs a = a_in;
+  a.trace = g_trace;
+  a.trace_flags = env_int("BSGL_FLAT_ORDER", 0);
   hipError_t e = a.dtype == kBF16 ? launch_tag<bf16_tag>(a, stream) : launch_tag<f16_tag>(a, stream);
   if (e != hipSuccess || decode_direct_out(a) || a.counters != nullptr) return e;
   MergeArgs mg;

@@ -53,9 +53,22 @@ extern "C" {
  * The KV write may then be fused into the decode kernel instead of being a
  * launch of its own; without the flag the write is always a separate launch. */
 #define BSGL_DECODE_FUSE_KV_WRITE 0x100
+/* OR into `variant` of bsgl_paged_decode to cut every request into exactly
+ * n_splits equal pieces.  By default (matrix-core kernel) n_splits is only the
+ * MOST pieces a request may get: pieces have one batch-wide length, about
+ * sum(seq_lens) / (batch * ceil(n_splits / 2)) tokens, so that ragged batches
+ * load every workgroup alike.  Results agree to rounding either way. */
+#define BSGL_DECODE_UNIFORM_SPLITS 0x200
 
 /* ABI version of this header (bumped on any signature change). */
 int bsgl_abi_version(void);
+
+/* Tuning aid with no counterpart in the reference: when device_buf is not NULL,
+ * every later matrix-core decode launch of this process writes 8 x uint64 per
+ * workgroup into it (launch order): start, end of prologue, end of streaming, end
+ * (100 MHz ticks; top bit of the last = this workgroup merged), XCC id, hardware
+ * id, row, piece | pieces << 32.  The buffer must hold the largest grid. */
+void bsgl_debug_decode_trace(void* device_buf);
 
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char* bsgl_last_error(void);

@@ -30,8 +30,10 @@ def test_symbol_exported(name):
 
 def test_host_arithmetic():
     assert _hip.lib.bsgl_abi_version() == _hip.ABI_VERSION
-    assert _hip.decode_num_splits(64, 2, 4096) == 8  # 64 requests x 2 kv heads x 8 = 1024 workgroups
-    assert _hip.decode_num_splits(64, 1, 4096) == 16
+    # 64 requests x 2 kv heads x 8 pieces = 1024 workgroups, and twice that as the most
+    # pieces one request may be cut into (length-balanced pieces)
+    assert _hip.decode_num_splits(64, 2, 4096) == 16
+    assert _hip.decode_num_splits(64, 1, 4096) == 32
     assert _hip.decode_num_splits(4096, 2, 4096) == 1
     assert _hip.decode_num_splits(1, 2, 100) == 1  # one short request: a single chunk
     assert _hip.decode_workspace_bytes(64, 12, 128, 1) == 0

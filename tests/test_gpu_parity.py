@@ -193,7 +193,8 @@ def test_fused_kv_write_and_merge(gpu, dtype, hq, hkv, monkeypatch):
     """The decode kernel that stores the new token itself and merges its own
     splits must agree bit for bit with the three-launch form (scatter kernel,
     decode, merge kernel) on output, lse and slab contents -- twice in a row on
-    one workspace, the second call with fewer requests."""
+    one workspace, the second call with fewer requests.  (Equal pieces per
+    request in both forms: the three-launch form cannot cut by length.)"""
     from baby_sglang_amd import _hip
 
     dim = 128
@@ -218,7 +219,7 @@ def test_fused_kv_write_and_merge(gpu, dtype, hq, hkv, monkeypatch):
             out = _hip.paged_decode(q[:n_req], k_slab, v_slab, r2t.req_to_token, rows[:n_req], seq[:n_req],
                                     n_splits=7, variant=2, lse=lse, workspace=ws,
                                     k_new=k_new[:n_req], v_new=v_new[:n_req], out_cache_loc=loc[:n_req],
-                                    fuse_kv_write=fused)
+                                    fuse_kv_write=fused, uniform_splits=True)
             torch.cuda.synchronize()
             results.append((out.clone(), lse.clone(), k_slab.clone(), v_slab.clone()))
         for a, b in zip(*results):
@@ -231,6 +232,32 @@ def test_fused_kv_write_and_merge(gpu, dtype, hq, hkv, monkeypatch):
         want = orc.decode_exact(cpu["q"][:n_req], k_ref, v_ref, cpu["req_to_token"], rows[:n_req].cpu(), seq[:n_req].cpu())
         assert_close(results[0][0], want, dtype, "fused decode")
         assert torch.equal(results[0][2].cpu(), k_ref) and torch.equal(results[0][3].cpu(), v_ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_length_balanced_splits(gpu, dtype):
+    """Pieces of one batch-wide length: a request gets between 1 and n_splits of
+    them.  One very long request among short ones, zero-length requests, and a
+    second call with other lengths on the same workspace (tickets back at zero)."""
+    from baby_sglang_amd import _hip
+
+    hq, hkv, dim = 12, 2, 128
+    ws = _hip.new_decode_workspace(_hip.decode_workspace_bytes(9, hq, dim, 16), gpu)
+    for seed, seq_lens in enumerate(([3000, 5, 17, 0, 200, 64, 1, 900, 31], [40, 40, 0, 2100], [1, 1, 1])):
+        cpu, r2t, kv = random_decode_problem(gpu, dtype, hq, hkv, dim, seq_lens, seed=31 + seed)
+        want, want_lse = orc.decode_exact(cpu["q"], cpu["k_slab"], cpu["v_slab"], cpu["req_to_token"],
+                                          cpu["req_pool_indices"], cpu["seq_lens"], return_lse=True)
+        k_slab, v_slab = kv.get_kv_buffer(0)
+        for n_splits in (16, 5, 2):
+            lse = torch.empty((len(seq_lens), hq), dtype=torch.float32, device=gpu)
+            out = _hip.paged_decode(cpu["q"].to(gpu), k_slab, v_slab, r2t.req_to_token,
+                                    cpu["req_pool_indices"].to(gpu), cpu["seq_lens"].to(gpu),
+                                    n_splits=n_splits, variant=2, lse=lse, workspace=ws)
+            torch.cuda.synchronize()
+            assert_close(out, want, dtype, f"balanced splits={n_splits} lens={seq_lens}")
+            live = torch.tensor(seq_lens) > 0
+            assert torch.allclose(lse.double().cpu()[live], want_lse[live], rtol=1e-4, atol=2e-3)
+            assert int(ws[: _hip.lib.bsgl_decode_counter_bytes()].max()) == 0
 
 
 def test_decode_empty_and_zero_length(gpu):
