@@ -40,7 +40,8 @@ def init_tp(backend: Optional[str] = None) -> Tuple[int, int, object]:
 
     if world_size > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # BABYSGL_TP_BACKEND=gloo lets several ranks rehearse on one GPU (RCCL wants a GPU per rank)
+            backend = os.getenv("BABYSGL_TP_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kwargs = {}
         if backend == "nccl":
             kwargs["device_id"] = torch.device("cuda", local_rank)
@@ -71,6 +72,12 @@ def tp_all_gather(x: torch.Tensor, tp_group) -> torch.Tensor:
     if world == 1:
         return x
     out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    if x.is_cuda and dist.get_backend(tp_group) == "gloo":
+        # gloo has no device all-gather: stage through host memory (rehearsals only; RCCL is the GPU path)
+        host = torch.empty(out.shape, dtype=x.dtype)
+        dist.all_gather_into_tensor(host, x.contiguous().cpu(), group=tp_group)
+        out.copy_(host)
+        return out
     dist.all_gather_into_tensor(out, x.contiguous(), group=tp_group)
     return out
 

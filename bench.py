@@ -55,6 +55,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-fuse", action="store_true", help="KV write as its own launch instead of inside the decode kernel")
     ap.add_argument("--no-extras", action="store_true", help="skip the contiguous-table and eager/graph side measurements")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1 GPUs: weak = N x batch requests over the tensor-parallel group (per-GPU KV bytes fixed), "
+                         "strong = the same batch cut N ways")
     return ap.parse_args()
 
 
@@ -315,6 +318,11 @@ def main():
 
     rank, world, tp_group = pkg.init_tp()
     dev = torch.device("cuda", torch.cuda.current_device())
+    per_gpu_batch = args.batch
+    if world > 1 and args.scaling == "weak":
+        # tensor parallel over all requests of the job: every rank holds its kv-head / sequence
+        # share of N x batch requests, i.e. the KV bytes of `batch` whole requests
+        args.batch *= world
     layout = pkg.TPLayout(rank, world, 12, 2)
     wl = Workload(args, dev, layout)
 
@@ -335,7 +343,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
-        "scaling": "strong" if world > 1 else "weak",
+        "scaling": args.scaling if world > 1 else "weak",
         "vs_baseline": None,
         "dtype": "bf16",
         "data": "synthetic (N(0,1) q/k/v and KV slabs, random-permutation page table, torch.manual_seed)",
@@ -344,6 +352,7 @@ def main():
                         f"{args.layers} layers x (KV write + paged decode attention), Hq=12 Hkv=2 D=128, "
                         f"page table={args.table}, kv_layout={args.kv_layout}",
             "global_batch": args.batch,
+            "kv_bytes_per_gpu_equal_to_batch": per_gpu_batch if args.scaling == "weak" or world == 1 else args.batch / world,
             "seq_len": args.seq,
             "parallelism": "single GPU" if world == 1 else
                            f"tp{world} = {layout.tp_kv} kv-head shards x {layout.tp_seq} sequence slices, one all-gather per layer",
@@ -381,6 +390,10 @@ def main():
             "avg_launch_us": ev_ms * 1e3,
         }
         result["step_hbm_gbs"] = total_b * args.layers / (ms_per_step * 1e-3) / 1e9
+        if world > 1:
+            # the exchange step broken out: decode launches alone vs the whole step
+            result["attention_only_ms_per_step"] = ev_ms * args.layers
+            result["exchange_ms_per_step"] = max(0.0, ms_per_step - ev_ms * args.layers)
 
     if world == 1 and not args.no_extras:
         extras = {}
