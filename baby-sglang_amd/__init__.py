@@ -11,6 +11,7 @@ from . import _hip
 from .attn_backend import SimpleAttentionBackend
 from .forward_batch import SimplifiedForwardBatch
 from .memory_pool import BaseTokenToKVPool, MHATokenToKVPool, ReqToTokenPool
+from .qwen2_hip import BabyQwen2ForCausalLM
 from .tp_runtime import (
     TPLayout,
     init_tp,
@@ -23,6 +24,7 @@ from .tp_runtime import (
 __all__ = [
     "_hip",
     "SimpleAttentionBackend",
+    "BabyQwen2ForCausalLM",
     "SimplifiedForwardBatch",
     "BaseTokenToKVPool",
     "MHATokenToKVPool",

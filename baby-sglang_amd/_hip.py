@@ -70,6 +70,11 @@ SIGNATURES = {
         ctypes.c_int,
         [_vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     ),
+    "bsgl_rmsnorm": (ctypes.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _f32, _i32, _vp]),
+    "bsgl_rope_kv_write": (
+        ctypes.c_int,
+        [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    ),
 }
 
 
@@ -353,3 +358,82 @@ def merge_attn_states(
     )  # fmt: skip
     _check(rc, "bsgl_merge_attn_states")
     return out
+
+
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, residual: Optional[torch.Tensor] = None):
+    """``(weight * norm(x + residual), x + residual)`` for ``[rows, hidden]`` inputs
+    (``residual`` optional: then the second result is ``None``), one launch."""
+    _need_gpu(x, weight)
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("x must be [rows, hidden] with unit column stride")
+    rows, hidden = x.shape
+    if weight.dtype != x.dtype or weight.shape != (hidden,) or not weight.is_contiguous():
+        raise ValueError("weight must be a dense [hidden] tensor of x's dtype")
+    out = torch.empty((rows, hidden), dtype=x.dtype, device=x.device)
+    res_out = None
+    if residual is not None:
+        _need_gpu(residual)
+        if residual.shape != x.shape or residual.dtype != x.dtype:
+            raise ValueError("residual must match x")
+        residual = residual if residual.is_contiguous() else residual.contiguous()
+        res_out = torch.empty((rows, hidden), dtype=x.dtype, device=x.device)
+    rc = lib.bsgl_rmsnorm(
+        out.data_ptr(), out.stride(0), res_out.data_ptr() if res_out is not None else None,
+        x.data_ptr(), x.stride(0), residual.data_ptr() if residual is not None else None,
+        weight.data_ptr(), rows, hidden, eps, _dtype_code(x), _stream_ptr(x.device),
+    )  # fmt: skip
+    _check(rc, "bsgl_rmsnorm")
+    return out, res_out
+
+
+def rope_kv_write(
+    qkv: torch.Tensor,
+    positions: torch.Tensor,
+    inv_freq: torch.Tensor,
+    n_q_heads: int,
+    n_kv_heads: int,
+    head_dim: int,
+    k_slab: Optional[torch.Tensor] = None,
+    v_slab: Optional[torch.Tensor] = None,
+    out_cache_loc: Optional[torch.Tensor] = None,
+    return_kv: bool = False,
+):
+    """Split a ``[T, (Hq + 2 Hkv) * D]`` projection row into q | k | v, rotate q and k,
+    store rotated k and v at slab rows ``out_cache_loc`` (when given) and return
+    ``(q [T, Hq, D], k or None, v or None)`` -- k and v only with ``return_kv``."""
+    _need_gpu(qkv, positions, inv_freq)
+    if qkv.dim() != 2 or qkv.stride(1) != 1 or qkv.shape[1] != (n_q_heads + 2 * n_kv_heads) * head_dim:
+        raise ValueError("qkv must be [T, (n_q_heads + 2 n_kv_heads) * head_dim] with unit column stride")
+    n_tok = qkv.shape[0]
+    if positions.dtype != torch.int64 or not positions.is_contiguous() or positions.shape[0] != n_tok:
+        positions = positions.to(torch.int64).contiguous()
+    if inv_freq.dtype != torch.float32 or not inv_freq.is_contiguous():
+        inv_freq = inv_freq.float().contiguous()
+    if inv_freq.numel() != head_dim // 2:
+        raise ValueError("inv_freq must have head_dim / 2 entries")
+    q = torch.empty((n_tok, n_q_heads, head_dim), dtype=qkv.dtype, device=qkv.device)
+    k = v = None
+    if return_kv or out_cache_loc is None:
+        k = torch.empty((n_tok, n_kv_heads, head_dim), dtype=qkv.dtype, device=qkv.device)
+        v = torch.empty((n_tok, n_kv_heads, head_dim), dtype=qkv.dtype, device=qkv.device)
+    loc = None
+    slab = (None, None, 0, 0)
+    if out_cache_loc is not None:
+        if k_slab is None or v_slab is None:
+            raise ValueError("out_cache_loc needs k_slab and v_slab")
+        _need_gpu(k_slab, v_slab, out_cache_loc)
+        if k_slab.dtype != qkv.dtype or v_slab.dtype != qkv.dtype or k_slab.stride(0) != v_slab.stride(0):
+            raise ValueError("KV slabs must have qkv's dtype and share a row stride")
+        loc = out_cache_loc if out_cache_loc.dtype == torch.int32 else out_cache_loc.to(torch.int32)
+        loc = loc if loc.is_contiguous() else loc.contiguous()
+        if loc.shape[0] != n_tok:
+            raise ValueError("out_cache_loc must have one slot per token")
+        slab = (k_slab.data_ptr(), v_slab.data_ptr(), k_slab.stride(0), k_slab.shape[0])
+    rc = lib.bsgl_rope_kv_write(
+        q.data_ptr(), q.stride(0), k.data_ptr() if k is not None else None, v.data_ptr() if v is not None else None,
+        k.stride(0) if k is not None else 0, qkv.data_ptr(), qkv.stride(0), positions.data_ptr(), inv_freq.data_ptr(),
+        *slab, loc.data_ptr() if loc is not None else None, n_tok, n_q_heads, n_kv_heads, head_dim,
+        _dtype_code(qkv), _stream_ptr(qkv.device),
+    )  # fmt: skip
+    _check(rc, "bsgl_rope_kv_write")
+    return q, k, v

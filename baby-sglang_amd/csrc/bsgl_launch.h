@@ -141,6 +141,46 @@ hipError_t launch_decode_mfma(const DecodeArgs& a, hipStream_t stream);
 // timestamps into (NULL switches it off); process-wide, not thread safe
 void set_decode_trace(uint64_t* buf);
 
+struct NormArgs {
+  void* out;
+  void* residual_out;    // optional: x + residual
+  const void* x;
+  const void* residual;  // optional
+  const void* weight;
+  int64_t x_row_stride;
+  int64_t out_row_stride;
+  int32_t rows;
+  int32_t hidden;
+  float eps;
+  int32_t dtype;
+};
+
+struct RopeArgs {
+  void* q_out;
+  int64_t q_out_row_stride;
+  void* k_out;  // optional rotated k rows
+  void* v_out;  // optional v rows
+  int64_t kv_out_row_stride;
+  const void* qkv;  // [n_tok, (n_q_heads + 2 n_kv_heads) * head_dim]
+  int64_t qkv_row_stride;
+  const int64_t* positions;
+  const float* inv_freq;  // [head_dim / 2]
+  void* k_slab;
+  void* v_slab;
+  int64_t slab_row_stride;
+  int64_t n_slots;
+  const int32_t* out_cache_loc;  // optional: slots to write rotated k and v into
+  int32_t n_tok;
+  int32_t n_q_heads;
+  int32_t n_kv_heads;
+  int32_t head_dim;
+  int32_t dtype;
+};
+
+hipError_t launch_rmsnorm(const NormArgs& a, hipStream_t stream);
+int rmsnorm_max_hidden(int dtype);
+hipError_t launch_rope_kv(const RopeArgs& a, hipStream_t stream);
+
 hipError_t launch_merge(const MergeArgs& a, hipStream_t stream);
 hipError_t launch_kv_scatter(const ScatterArgs& a, hipStream_t stream);
 hipError_t launch_prefill_expand(const ExpandArgs& a, hipStream_t stream);

@@ -418,4 +418,89 @@ int bsgl_merge_attn_states(void* out, int64_t out_row_stride, float* lse_out, co
   return BSGL_OK;
 }
 
+int bsgl_rmsnorm(void* out, int64_t out_row_stride, void* residual_out, const void* x, int64_t x_row_stride,
+                 const void* residual, const void* weight, int32_t rows, int32_t hidden, float eps,
+                 int32_t dtype, void* stream) {
+  if (int rc = check_dtype(dtype)) return rc;
+  if (rows < 0 || hidden <= 0) return fail(BSGL_ERR_BAD_ARG, "rows < 0 or hidden <= 0");
+  if (rows == 0) return BSGL_OK;
+  if (!out || !x || !weight) return fail(BSGL_ERR_BAD_ARG, "null device pointer (out/x/weight)");
+  if (residual_out != nullptr && residual == nullptr)
+    return fail(BSGL_ERR_BAD_ARG, "residual_out without residual");
+  const int eb = bsgl::dtype_bytes(dtype);
+  if ((hidden * eb) % 16) return fail(BSGL_ERR_UNSUPPORTED, "hidden size %d is not a multiple of 16 bytes", hidden);
+  if (hidden > bsgl::rmsnorm_max_hidden(dtype))
+    return fail(BSGL_ERR_UNSUPPORTED, "hidden size %d above %d", hidden, bsgl::rmsnorm_max_hidden(dtype));
+  if (!aligned16(out) || !aligned16(x) || !aligned16(weight) || !aligned16(residual) || !aligned16(residual_out))
+    return fail(BSGL_ERR_BAD_ARG, "out, x, weight and residuals must be 16-byte aligned");
+  if ((x_row_stride * eb) % 16 || (out_row_stride * eb) % 16 || x_row_stride < hidden || out_row_stride < hidden)
+    return fail(BSGL_ERR_BAD_ARG, "row strides must be multiples of 16 bytes and at least hidden");
+  bsgl::NormArgs a{};
+  a.out = out;
+  a.residual_out = residual_out;
+  a.x = x;
+  a.residual = residual;
+  a.weight = weight;
+  a.x_row_stride = x_row_stride;
+  a.out_row_stride = out_row_stride;
+  a.rows = rows;
+  a.hidden = hidden;
+  a.eps = eps;
+  a.dtype = dtype;
+  const hipError_t e = bsgl::launch_rmsnorm(a, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail("rmsnorm launch", e);
+  return BSGL_OK;
+}
+
+int bsgl_rope_kv_write(void* q_out, int64_t q_out_row_stride, void* k_out, void* v_out, int64_t kv_out_row_stride,
+                       const void* qkv, int64_t qkv_row_stride, const int64_t* positions, const float* inv_freq,
+                       void* k_slab, void* v_slab, int64_t slab_row_stride, int64_t n_slots,
+                       const int32_t* out_cache_loc, int32_t n_tok, int32_t n_q_heads, int32_t n_kv_heads,
+                       int32_t head_dim, int32_t dtype, void* stream) {
+  if (int rc = check_dtype(dtype)) return rc;
+  if (n_tok < 0) return fail(BSGL_ERR_BAD_ARG, "n_tok < 0");
+  if (n_tok == 0) return BSGL_OK;
+  if (!q_out || !qkv || !positions || !inv_freq) return fail(BSGL_ERR_BAD_ARG, "null device pointer (q_out/qkv/positions/inv_freq)");
+  if (n_q_heads <= 0 || n_kv_heads <= 0 || head_dim <= 0) return fail(BSGL_ERR_BAD_ARG, "head counts and head_dim must be positive");
+  const int eb = bsgl::dtype_bytes(dtype);
+  if (head_dim > 256 || (head_dim / 2 * eb) % 16 || head_dim % 2)
+    return fail(BSGL_ERR_UNSUPPORTED, "head_dim %d: half a head row must be a multiple of 16 bytes, head_dim <= 256", head_dim);
+  if ((k_out == nullptr) != (v_out == nullptr)) return fail(BSGL_ERR_BAD_ARG, "k_out and v_out go together");
+  if (out_cache_loc != nullptr && (!k_slab || !v_slab || n_slots <= 0))
+    return fail(BSGL_ERR_BAD_ARG, "out_cache_loc given without KV slabs");
+  if (out_cache_loc == nullptr && k_out == nullptr)
+    return fail(BSGL_ERR_BAD_ARG, "neither a cache write (out_cache_loc) nor k_out / v_out requested");
+  const int64_t q_cols = (int64_t)n_q_heads * head_dim, kv_cols = (int64_t)n_kv_heads * head_dim;
+  if (!aligned16(q_out) || !aligned16(qkv) || !aligned16(k_out) || !aligned16(v_out) || !aligned16(k_slab) || !aligned16(v_slab))
+    return fail(BSGL_ERR_BAD_ARG, "q_out, qkv, k_out, v_out and slabs must be 16-byte aligned");
+  if ((q_out_row_stride * eb) % 16 || (qkv_row_stride * eb) % 16 || (kv_out_row_stride * eb) % 16 || (slab_row_stride * eb) % 16)
+    return fail(BSGL_ERR_BAD_ARG, "row strides must be multiples of 16 bytes");
+  if (q_out_row_stride < q_cols || qkv_row_stride < q_cols + 2 * kv_cols || (k_out && kv_out_row_stride < kv_cols) ||
+      (out_cache_loc && slab_row_stride < kv_cols))
+    return fail(BSGL_ERR_BAD_ARG, "a row stride is shorter than its row");
+  bsgl::RopeArgs a{};
+  a.q_out = q_out;
+  a.q_out_row_stride = q_out_row_stride;
+  a.k_out = k_out;
+  a.v_out = v_out;
+  a.kv_out_row_stride = kv_out_row_stride;
+  a.qkv = qkv;
+  a.qkv_row_stride = qkv_row_stride;
+  a.positions = positions;
+  a.inv_freq = inv_freq;
+  a.k_slab = k_slab;
+  a.v_slab = v_slab;
+  a.slab_row_stride = slab_row_stride;
+  a.n_slots = n_slots;
+  a.out_cache_loc = out_cache_loc;
+  a.n_tok = n_tok;
+  a.n_q_heads = n_q_heads;
+  a.n_kv_heads = n_kv_heads;
+  a.head_dim = head_dim;
+  a.dtype = dtype;
+  const hipError_t e = bsgl::launch_rope_kv(a, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail("rope launch", e);
+  return BSGL_OK;
+}
+
 }  // extern "C"

@@ -189,6 +189,41 @@ int bsgl_merge_attn_states(void* out /*device*/, int64_t out_row_stride,
                            int32_t n_parts, int32_t rows, int32_t n_heads, int32_t head_dim,
                            int32_t dtype, void* stream);
 
+/*
+ * The steps either side of the attention call (the reference's next callers).
+ *
+ * RMSNorm with optional residual add.  Replaces RMSNorm.forward (qwen2.py:125-141):
+ *   h = x + residual (rounded to dtype; h = x when residual is NULL); residual_out = h
+ *   out = weight * dtype(float(h) * rsqrt(mean(float(h)^2) + eps))
+ * x / out rows may be strided views (strides in elements); residual, residual_out and
+ * weight are dense.  residual_out may alias residual, out may alias x.
+ */
+int bsgl_rmsnorm(void* out /*device*/, int64_t out_row_stride, void* residual_out /*device or NULL*/,
+                 const void* x /*device*/, int64_t x_row_stride, const void* residual /*device or NULL*/,
+                 const void* weight /*device, [hidden]*/, int32_t rows, int32_t hidden, float eps,
+                 int32_t dtype, void* stream);
+
+/*
+ * Rotary embedding of q and k, fused with the QKV split and the KV-cache write.
+ * Replaces RotaryEmbedding.forward (qwen2.py:246-268: half-split rotation, cos / sin of
+ * float(position) * inv_freq cast to dtype before the multiply), the split of the
+ * projection row into q | k | v (qwen2.py:285-290) and MHATokenToKVPool.set_kv_buffer
+ * (memory_pool.py:152-171).  qkv is [n_tok, (n_q_heads + 2 n_kv_heads) * head_dim];
+ * rotated q goes to q_out [n_tok, n_q_heads * head_dim]; rotated k and v go to
+ * k_slab / v_slab rows out_cache_loc[t] (slots outside [0, n_slots) are skipped) when
+ * out_cache_loc is not NULL, and to k_out / v_out [n_tok, n_kv_heads * head_dim] when
+ * those are not NULL (at least one destination is required).
+ */
+int bsgl_rope_kv_write(void* q_out /*device*/, int64_t q_out_row_stride,
+                       void* k_out /*device or NULL*/, void* v_out /*device or NULL*/, int64_t kv_out_row_stride,
+                       const void* qkv /*device*/, int64_t qkv_row_stride,
+                       const int64_t* positions /*device, [n_tok]*/, const float* inv_freq /*device, [head_dim/2]*/,
+                       void* k_slab /*device or NULL*/, void* v_slab /*device or NULL*/,
+                       int64_t slab_row_stride, int64_t n_slots,
+                       const int32_t* out_cache_loc /*device, [n_tok], or NULL*/,
+                       int32_t n_tok, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim,
+                       int32_t dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
