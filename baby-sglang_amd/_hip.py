@@ -47,6 +47,7 @@ SIGNATURES = {
     "bsgl_abi_version": (ctypes.c_int, []),
     "bsgl_last_error": (ctypes.c_char_p, []),
     "bsgl_debug_decode_trace": (None, [_vp]),
+    "bsgl_debug_prefill_profile": (None, [_vp]),
     "bsgl_kv_scatter": (
         ctypes.c_int,
         [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp],

@@ -99,8 +99,9 @@ struct ExpandArgs {
   int32_t batch;
   int32_t total_q_tokens;
   int64_t* cu_ext;   // [batch + 1] running sum of extended_lens
-  int64_t* cu_blk;   // [batch + 1] running sum of ceil(extended_lens / blk_rows); may be NULL
+  int64_t* cu_blk;   // [batch + 1] running sum of block GROUPS: ceil(ceil(extended_lens / blk_rows) / grp_blocks); may be NULL
   int32_t blk_rows;  // 16 or 64 (0 counts as 16)
+  int32_t grp_blocks;  // blocks per group (0 counts as 1)
   int64_t* row_req;  // [total_q_tokens]; may be NULL (then only the running sums are made)
   int64_t* row_len;  // [total_q_tokens]
 };
@@ -117,11 +118,13 @@ struct PrefillArgs {
   const int64_t* prefix_lens;
   const int64_t* extended_lens;
   const int64_t* cu_ext;
-  const int64_t* cu_blk;
+  const int64_t* cu_blk;  // running sum of block groups per request (ExpandArgs::cu_blk)
   int32_t batch;
   int32_t total_q_tokens;
   int32_t blk_rows;    // query positions per workgroup: 16 or 64
-  int32_t max_blocks;  // grid bound: ceil(total_q_tokens / blk_rows) + batch
+  int32_t grp_blocks;  // consecutive blocks of a request that form one group (share an XCD)
+  int32_t max_groups;  // bound on cu_blk[batch]
+  uint64_t* prof;      // tuning aid, normally NULL: 6 x uint64 of phase cycles per wave
   int32_t n_q_heads;
   int32_t n_kv_heads;
   int32_t head_dim;

@@ -135,6 +135,9 @@ int bsgl_abi_version(void) { return 1; }
 
 void bsgl_debug_decode_trace(void* device_buf) { bsgl::set_decode_trace((uint64_t*)device_buf); }
 
+static uint64_t* g_prefill_prof = nullptr;
+void bsgl_debug_prefill_profile(void* device_buf) { g_prefill_prof = (uint64_t*)device_buf; }
+
 const char* bsgl_last_error(void) { return g_err; }
 
 int bsgl_kv_scatter(void* k_slab, void* v_slab, int64_t slab_row_stride, int64_t n_slots,
@@ -340,9 +343,17 @@ int bsgl_paged_prefill(void* out, int64_t out_row_stride, const void* q, int64_t
   pa.total_q_tokens = total_q_tokens;
   // 64 query positions per workgroup unless the extends are very short on average
   pa.blk_rows = (int64_t)total_q_tokens >= 24ll * batch ? 64 : 16;
-  if (env_int("BSGL_PREFILL_BLK", 0) == 16 || env_int("BSGL_PREFILL_BLK", 0) == 64) pa.blk_rows = env_int("BSGL_PREFILL_BLK", 0);
+  {
+    const int forced = env_int("BSGL_PREFILL_BLK", 0);  // tuning override
+    if (forced == 16 || forced == 64) pa.blk_rows = forced;
+  }
   ex.blk_rows = pa.blk_rows;
-  pa.max_blocks = (total_q_tokens + pa.blk_rows - 1) / pa.blk_rows + batch;
+  // groups of 8 consecutive blocks of a request share an XCD (and with it an L2)
+  pa.grp_blocks = env_int("BSGL_PREFILL_GROUP", 8) > 0 ? env_int("BSGL_PREFILL_GROUP", 8) : 8;
+  ex.grp_blocks = pa.grp_blocks;
+  // bound on the number of (request, block group) entries: sum ceil(blocks_i / g) <= blocks / g + batch
+  pa.max_groups = ((total_q_tokens + pa.blk_rows - 1) / pa.blk_rows + batch) / pa.grp_blocks + batch + 1;
+  pa.prof = g_prefill_prof;
   pa.n_q_heads = n_q_heads;
   pa.n_kv_heads = n_kv_heads;
   pa.head_dim = head_dim;

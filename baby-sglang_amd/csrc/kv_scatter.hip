@@ -31,19 +31,20 @@ __global__ __launch_bounds__(256) void kv_scatter_kernel(ScatterArgs a) {
   *(uint4*)((char*)a.v_slab + dst) = vv;
 }
 
-// exclusive running sums of extended_lens and of ceil(extended_lens / blk_rows)
-// (negative lengths count as 0)
+// exclusive running sums of extended_lens and of the block groups of each request,
+// ceil(ceil(extended_lens / blk_rows) / grp_blocks)  (negative lengths count as 0)
 __global__ void prefill_cu_kernel(ExpandArgs a) {
   __shared__ int64_t s_ext[256], s_blk[256];
   const int tid = threadIdx.x;
   const int per = (a.batch + 255) / 256;
   const int lo = min(tid * per, a.batch), hi = min(lo + per, a.batch);
   const int64_t br = a.blk_rows > 0 ? a.blk_rows : 16;
+  const int64_t gb = a.grp_blocks > 0 ? a.grp_blocks : 1;
   int64_t sum = 0, blocks = 0;
   for (int i = lo; i < hi; ++i) {
     const int64_t e = max((int64_t)0, a.extended_lens[i]);
     sum += e;
-    blocks += (e + br - 1) / br;
+    blocks += ((e + br - 1) / br + gb - 1) / gb;
   }
   s_ext[tid] = sum;
   s_blk[tid] = blocks;
@@ -67,7 +68,7 @@ __global__ void prefill_cu_kernel(ExpandArgs a) {
     a.cu_ext[i] = run;
     if (a.cu_blk != nullptr) a.cu_blk[i] = brun;
     run += e;
-    brun += (e + br - 1) / br;
+    brun += ((e + br - 1) / br + gb - 1) / gb;
   }
 }
 

@@ -25,11 +25,13 @@
 // the step after next will overwrite (3-stage ring).
 //
 // Work list without a host read: prefill_cu_kernel writes the running sums of
-// extended_lens and of ceil(extended_lens / 16); workgroup b finds its request by
-// binary search and exits if b is past the last block.
+// extended_lens and of each request's block groups; a workgroup finds its request by
+// binary search and exits if it is past the last group or block.
 #include "bsgl_device.h"
 #include "bsgl_launch.h"
 #include "bsgl_mfma.h"
+
+#include <type_traits>
 
 namespace bsgl {
 
@@ -67,25 +69,42 @@ void prefill_mfma_kernel(PrefillArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lq = lane & 15;  // query position inside the wave's 16 (column of S^T, row of O)
   const int lg = lane >> 4;
-  const int kvh = blockIdx.y;
   const int G = a.n_q_heads / a.n_kv_heads;
-  const int rt0 = blockIdx.z * RT;           // first q head of the group handled here
-  const int n_rt = min(RT, G - rt0);         // heads past it compute on zero queries and are not written
 
-  // ---- which (request, block of 16 * WAVES positions) is this? ---------------------------
-  // launch order is reversed: a request's last blocks see the most tokens and go first
-  const int64_t n_blocks = a.cu_blk[a.batch];
-  if ((int64_t)blockIdx.x >= n_blocks) return;
-  const int64_t blk_id = n_blocks - 1 - (int64_t)blockIdx.x;
-  int lo = 0, hi = a.batch;  // last request with cu_blk[lo] <= blk_id
+  // ---- which (request, block of 16 * WAVES positions, kv head, q-head slice) is this? -------
+  // Workgroups are dealt to the 8 XCDs round-robin by launch index, and each XCD has its own
+  // L2.  The workgroups that stream the same K/V rows -- the blocks of one request x one kv
+  // head x all q-head slices -- are therefore given launch indices that are EQUAL modulo 8
+  // and adjacent in that XCD's sequence: index = 8 * slot + xcd, slot = (local group,
+  // block in group, slice).  A group is grp_blocks consecutive blocks of a request (so that
+  // one long prompt still spreads over all XCDs); group g of the (request, block group, kv
+  // head) list goes to XCD g % 8.  K/V then comes from HBM once per group instead of once
+  // per workgroup.  (Only placement depends on the dealing order, never the result.)
+  const int n_z = (G + RT - 1) / RT;
+  const int per_group = a.grp_blocks * n_z;
+  const unsigned slot = blockIdx.x >> 3;
+  const int64_t g = (int64_t)(slot / (unsigned)per_group) * 8 + (blockIdx.x & 7);
+  if (g >= a.cu_blk[a.batch] * a.n_kv_heads) return;
+  const int within = (int)(slot % (unsigned)per_group);
+  const int kvh = (int)(g % a.n_kv_heads);
+  const int64_t pg = g / a.n_kv_heads;       // (request, block group) index
+  const int rt0 = (within % n_z) * RT;       // first q head of the group handled here
+  const int n_rt = min(RT, G - rt0);         // heads past it compute on zero queries and are not written
+  int lo = 0, hi = a.batch;  // last request with cu_blk[lo] <= pg
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
-    if (a.cu_blk[mid] <= blk_id) lo = mid; else hi = mid;
+    if (a.cu_blk[mid] <= pg) lo = mid; else hi = mid;
   }
   const int i_req = lo;
-  const int q0_wg = (int)(blk_id - a.cu_blk[i_req]) * (16 * WAVES);
+  const int64_t ext_raw = a.extended_lens[i_req];
+  const int n_blocks = (int)(((ext_raw < 0 ? 0 : ext_raw) + 16 * WAVES - 1) / (16 * WAVES));
+  const int bg0 = (int)(pg - a.cu_blk[i_req]) * a.grp_blocks;  // first block of the group
+  const int nb = min(a.grp_blocks, n_blocks - bg0);            // blocks in it (>= 1)
+  if (within / n_z >= nb) return;
+  // a request's last blocks see the most tokens: they go first
+  const int q0_wg = (bg0 + nb - 1 - within / n_z) * (16 * WAVES);
   const int64_t ext64 = a.extended_lens[i_req];
-  const int rows_wg = (int)min((int64_t)(16 * WAVES), ext64 - q0_wg);  // >= 1 by construction of cu_blk
+  const int rows_wg = (int)min((int64_t)(16 * WAVES), ext64 - q0_wg);  // >= 1: the block exists
   const int q0 = q0_wg + 16 * wave;
   const int n_rows = max(0, min(16, rows_wg - 16 * wave));  // 0: this wave only helps to load
   const int64_t q_row0 = a.cu_ext[i_req] + q0;
@@ -99,6 +118,7 @@ void prefill_mfma_kernel(PrefillArgs a) {
   const int kv_len = min(seq, prefix + q0_wg + rows_wg);                 // what the workgroup streams
   const int wave_len = n_rows > 0 ? min(kv_len, prefix + q0 + n_rows) : 0;  // what this wave's rows can see
   const int my_last = min(prefix + q0 + min(lq, max(n_rows, 1) - 1), kv_len - 1);
+  const int full_until = min(prefix + q0, kv_len - 1);  // last token EVERY row of this wave sees
   const int32_t* table_row = a.kv.table + req * a.kv.table_row_stride;
   const uint32_t max_slot = (uint32_t)(a.kv.n_slots - 1);
   const uint32_t row_units = (uint32_t)(a.kv.slab_row_stride * 2 / 16);
@@ -134,6 +154,10 @@ void prefill_mfma_kernel(PrefillArgs a) {
   for (int n = 0; n < 8; ++n)
     v_off[n] = v_rec * REC + 256 + (((2 * n + ((lane >> 1) & 1)) ^ xr_of_rec(v_rec)) << 4) + ((lane & 1) << 3);
 
+  // tuning aid: cycles this wave spent waiting for its DMA, at the barrier, issuing DMA, in
+  // the score / softmax half and in the PV half of its steps, and the step count
+  const bool PROF = a.prof != nullptr;
+  uint64_t prof[6] = {0, 0, 0, 0, 0, 0};
   float m_run[RT], l_run[RT];
   f32x4 o_acc[RT][8];
 #pragma unroll
@@ -182,11 +206,16 @@ void prefill_mfma_kernel(PrefillArgs a) {
     if (n_steps > 1) issue_step(1);
 
     for (int step = 0; step < n_steps; ++step) {
+      const uint64_t t0 = PROF ? __builtin_readcyclecounter() : 0;
       // this wave's share of the step has landed (one younger step may stay in flight) ...
       if (step + 1 < n_steps) dma_wait<DPW>(); else dma_wait<0>();
+      const uint64_t t1 = PROF ? __builtin_readcyclecounter() : 0;
       // ... and so has everybody's; all waves are also done reading step - 1
       __syncthreads();
+      const uint64_t t2 = PROF ? __builtin_readcyclecounter() : 0;
       if (step + 2 < n_steps) issue_step(step + 2);  // into the stage step - 1 used
+      const uint64_t t3 = PROF ? __builtin_readcyclecounter() : 0;
+      if (PROF) { prof[0] += t1 - t0; prof[1] += t2 - t1; prof[2] += t3 - t2; prof[5] += 1; }
       const char* st = smem + (step % NSTAGE) * STEP_BYTES;
       const int tok0 = blk + step * STEP + 4 * lg;  // first of this lane's tokens in tile 0; tile 1: + 16
       if (blk + step * STEP >= wave_len) continue;  // nothing this wave's rows may see (wave-uniform)
@@ -198,6 +227,12 @@ void prefill_mfma_kernel(PrefillArgs a) {
         for (int s = 0; s < 4; ++s) kf[u][s] = *(const uint4*)(st + u * TILE_BYTES + k_off[s]);
 
       uint4 pf[RT][PFrag<Tag>::N];
+      const uint64_t t4 = PROF ? __builtin_readcyclecounter() : 0;
+      // scores, running max and probabilities of each q head for this step.  The running max
+      // is kept in raw score units and the scale enters once, inside the exponent:
+      // p = exp2(s * c - m * c) is one fused multiply-add per score.  Only steps that reach
+      // past what the wave's first row may see (causal edge or end of sequence) compare.
+      const bool step_masked = blk + step * STEP + STEP - 1 > full_until;  // wave-uniform
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         f32x4 sc[2];
@@ -207,21 +242,24 @@ void prefill_mfma_kernel(PrefillArgs a) {
 #pragma unroll
           for (int s = 0; s < 4; ++s) sc[u] = Mma<Tag>::qk(kf[u][s], qf[rt][s], sc[u]);
         }
-        float sv[8];
-        float tmax = kNegInf;
+        float raw[8];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            // causal + end of sequence
-            sv[4 * u + r] = (tok0 + 16 * u + r <= my_last) ? sc[u][r] * scale_log2e : kNegInf;
-            tmax = fmaxf(tmax, sv[4 * u + r]);
-          }
+          for (int r = 0; r < 4; ++r) raw[4 * u + r] = sc[u][r];
+        if (step_masked) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) raw[4 * u + r] = (tok0 + 16 * u + r <= my_last) ? raw[4 * u + r] : kNegInf;
+        }
+        float tmax = fmaxf(fmaxf(fmaxf(raw[0], raw[1]), fmaxf(raw[2], raw[3])),
+                           fmaxf(fmaxf(raw[4], raw[5]), fmaxf(raw[6], raw[7])));
         tmax = quad_group_max(tmax);
         if (__any(tmax > m_run[rt])) {
           const float m_new = fmaxf(m_run[rt], tmax);
           // a column with nothing visible yet keeps m = -inf: its factor is 1, not exp2(nan)
-          const float alpha = m_new == kNegInf ? 1.f : fast_exp2(m_run[rt] - m_new);
+          const float alpha = m_new == kNegInf ? 1.f : fast_exp2((m_run[rt] - m_new) * scale_log2e);
           m_run[rt] = m_new;
           l_run[rt] *= alpha;
           float ar[4];
@@ -232,11 +270,12 @@ void prefill_mfma_kernel(PrefillArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) o_acc[rt][n][r] *= ar[r];
         }
+        const float neg_mc = -(m_run[rt] == kNegInf ? 0.f : m_run[rt]) * scale_log2e;  // masked scores: exp2(-inf) = 0
         float pa[4], pb[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          pa[r] = m_run[rt] == kNegInf ? 0.f : fast_exp2(sv[r] - m_run[rt]);
-          pb[r] = m_run[rt] == kNegInf ? 0.f : fast_exp2(sv[4 + r] - m_run[rt]);
+          pa[r] = fast_exp2(fmaf(raw[r], scale_log2e, neg_mc));
+          pb[r] = fast_exp2(fmaf(raw[4 + r], scale_log2e, neg_mc));
           l_run[rt] += pa[r] + pb[r];
         }
         // k-values 0-3 of the lane: its tokens of tile 0, k-values 4-7: those of tile 1
@@ -244,6 +283,7 @@ void prefill_mfma_kernel(PrefillArgs a) {
 #pragma unroll
         for (int k = 0; k < PFrag<Tag>::N; ++k) pf[rt][k] = make_uint4(fa.f[k].x, fa.f[k].y, fb.f[k].x, fb.f[k].y);
       }
+      const uint64_t t5 = PROF ? __builtin_readcyclecounter() : 0;
 #pragma unroll
       for (int n = 0; n < 8; ++n) {
         const s16x4_t va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -257,9 +297,19 @@ void prefill_mfma_kernel(PrefillArgs a) {
 #pragma unroll
           for (int k = 0; k < PFrag<Tag>::N; ++k) o_acc[rt][n] = Mma<Tag>::pv32(pf[rt][k], vf, o_acc[rt][n]);
       }
+      if (PROF) {
+        const uint64_t t6 = __builtin_readcyclecounter();
+        prof[3] += t5 - t4;
+        prof[4] += t6 - t5;
+      }
     }
   }
 
+  if (PROF && lane == 0) {
+    uint64_t* dst = a.prof + 6 * ((uint64_t)blockIdx.x * WAVES + wave);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dst[i] = prof[i];
+  }
   // ---- normalise and write: rows through LDS so that a lane stores 16 contiguous bytes ----
   __syncthreads();  // the ring is free: each wave stages its rows in its own region
   float* o_lds = (float*)(smem + wave * STAGE_OUT);
@@ -288,7 +338,14 @@ void prefill_mfma_kernel(PrefillArgs a) {
 template <typename Tag, int RT>
 hipError_t launch_rt(const PrefillArgs& a, hipStream_t stream) {
   const int group = a.n_q_heads / a.n_kv_heads;
-  dim3 grid((unsigned)a.max_blocks, a.n_kv_heads, (group + RT - 1) / RT);
+  const int n_z = (group + RT - 1) / RT;
+  // 8 XCD sequences of ceil(groups / 8) local groups, grp_blocks * n_z workgroups each
+  const int64_t local_groups = ((int64_t)a.max_groups * a.n_kv_heads + 7) / 8;
+  const int64_t n_wg = 8 * local_groups * a.grp_blocks * n_z;
+  if (n_wg > 0x7fffffffll) return hipErrorInvalidValue;
+  dim3 grid((unsigned)n_wg, 1, 1);
+  // (8-wave workgroups of 128 positions were measured too: the barrier then costs 860 cycles a
+  // step instead of 280 and the kernel is 15 % slower)
   if (a.blk_rows == 64)
     hipLaunchKernelGGL((prefill_mfma_kernel<Tag, RT, 4>), grid, dim3(256), 0, stream, a);
   else

@@ -70,6 +70,12 @@ int bsgl_abi_version(void);
  * id, row, piece | pieces << 32.  The buffer must hold the largest grid. */
 void bsgl_debug_decode_trace(void* device_buf);
 
+/* Tuning aid with no counterpart in the reference: when device_buf is not NULL, every
+ * later matrix-core extend launch writes 6 x uint64 per wave (workgroup launch index x
+ * waves + wave): shader cycles spent waiting for its own DMA, at the barrier, issuing
+ * DMA, in the score / softmax half, in the PV half, and its step count. */
+void bsgl_debug_prefill_profile(void* device_buf);
+
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char* bsgl_last_error(void);
 

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--table", default="perm")
+    ap.add_argument("--profile", action="store_true", help="per-phase cycle counts of the matrix-core kernel")
     a = ap.parse_args()
     import baby_sglang_amd as pkg
 
@@ -67,6 +68,24 @@ def main():
     print(f"batch={a.batch} ext={a.ext} prefix={a.prefix} Hq={a.hq} Hkv={a.hkv} variant={a.variant} table={a.table}: "
           f"{ms:.3f} ms/layer  {flops / ms / 1e9:.1f} TFLOP/s  (KV of the batch {kv_bytes / 1e6:.0f} MB, "
           f"{a.batch * a.ext / ms * 1e3:.0f} extend tokens/s/layer)", flush=True)
+
+
+    if a.profile:
+        n_wave = 1 << 20
+        buf = torch.zeros((n_wave, 6), dtype=torch.int64, device=dev)
+        pkg._hip.lib.bsgl_debug_prefill_profile(buf.data_ptr())
+        call()
+        torch.cuda.synchronize()
+        pkg._hip.lib.bsgl_debug_prefill_profile(None)
+        t = buf.cpu()
+        t = t[t[:, 5] > 0].double()
+        steps = t[:, 5].sum()
+        names = ("own-DMA wait", "barrier", "DMA issue", "score+softmax", "PV")
+        tot = t[:, :5].sum()
+        print(f"  {len(t)} waves, {int(steps)} wave-steps; cycles per wave-step by phase:")
+        for i, n in enumerate(names):
+            print(f"    {n:14s} {t[:, i].sum() / steps:8.0f}  ({t[:, i].sum() / tot:6.1%})")
+        print(f"    {'sum':14s} {tot / steps:8.0f}")
 
 
 if __name__ == "__main__":
