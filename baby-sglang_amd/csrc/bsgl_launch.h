@@ -60,7 +60,6 @@ struct DecodeArgs {
   // tuning aid, normally NULL: 8 x uint64 per workgroup (in launch order): start, after
   // the prologue, after the streaming loop, end (100 MHz ticks), XCC id, HW id, row, piece
   uint64_t* trace;
-  int32_t trace_flags;
 };
 
 struct MergeArgs {

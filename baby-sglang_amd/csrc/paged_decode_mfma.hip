@@ -100,10 +100,11 @@ void decode_mfma_kernel(DecodeArgs a) {
   int flat_req = -1, flat_seq = 0;  // the row's page-table row and length, when found by the flat search
   if (a.balance_target > 0) {
     // ---- flat grid: which (row, piece) is this? -------------------------------------
-    const unsigned piece_cap = gridDim.x / (unsigned)n_hg;
-    const bool hg_major = a.trace_flags & 1;
-    hg = hg_major ? (int)(blockIdx.x / piece_cap) : (int)(blockIdx.x % (unsigned)n_hg);
-    const int piece = hg_major ? (int)(blockIdx.x % piece_cap) : (int)(blockIdx.x / (unsigned)n_hg);
+    // (head group fastest: the workgroups of a piece's kv heads run side by side and read the
+    // same DRAM pages together; measured 1 % faster than all pieces of a head group first, and
+    // equal to putting the two in one two-wave workgroup)
+    hg = (int)(blockIdx.x % (unsigned)n_hg);
+    const int piece = (int)(blockIdx.x / (unsigned)n_hg);
     // per-lane request data, 64 rows at a time; the first block is loaded once for both passes
     auto len_of = [&](int i) {
       const int64_t s64 = i < a.rows ? a.seq_lens[i] : 0;
@@ -555,7 +556,6 @@ hipError_t launch_decode_mfma(const DecodeArgs& a_in, hipStream_t stream) {
   if (a_in.rows == 0) return hipSuccess;
   DecodeArgs a = a_in;
   a.trace = g_trace;
-  a.trace_flags = env_int("BSGL_FLAT_ORDER", 0);
   hipError_t e = a.dtype == kBF16 ? launch_tag<bf16_tag>(a, stream) : launch_tag<f16_tag>(a, stream);
   if (e != hipSuccess || decode_direct_out(a) || a.counters != nullptr) return e;
   MergeArgs mg;

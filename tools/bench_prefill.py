@@ -24,12 +24,13 @@ def main():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--table", default="perm")
+    ap.add_argument("--dtype", choices=["bf16", "f16"], default="bf16")
     ap.add_argument("--profile", action="store_true", help="per-phase cycle counts of the matrix-core kernel")
     a = ap.parse_args()
     import baby_sglang_amd as pkg
 
     dev = torch.device("cuda:0")
-    dim, dtype = 128, torch.bfloat16
+    dim, dtype = 128, torch.bfloat16 if a.dtype == "bf16" else torch.float16
     seq = a.prefix + a.ext
     size = a.batch * seq
     gen = torch.Generator(device=dev).manual_seed(0)
@@ -65,7 +66,7 @@ def main():
     ms = e0.elapsed_time(e1) / a.reps
     flops = 4.0 * a.hq * dim * (a.ext * a.prefix + a.ext * (a.ext + 1) / 2) * a.batch
     kv_bytes = a.batch * seq * a.hkv * dim * 2 * 2
-    print(f"batch={a.batch} ext={a.ext} prefix={a.prefix} Hq={a.hq} Hkv={a.hkv} variant={a.variant} table={a.table}: "
+    print(f"{a.dtype} batch={a.batch} ext={a.ext} prefix={a.prefix} Hq={a.hq} Hkv={a.hkv} variant={a.variant} table={a.table}: "
           f"{ms:.3f} ms/layer  {flops / ms / 1e9:.1f} TFLOP/s  (KV of the batch {kv_bytes / 1e6:.0f} MB, "
           f"{a.batch * a.ext / ms * 1e3:.0f} extend tokens/s/layer)", flush=True)
 

@@ -102,6 +102,20 @@ def main():
     for c in sorted(set(load.tolist())):
         m = load == c
         print(f"  CUs holding {c} workgroups: {int(m.sum())} workgroups, stream median {loop[m].median():.2f} us")
+    rows_ = (t[:, 6] & 0xFFFFFFFF)[ran]
+    team = rows_ * 64 + (t[:, 6] >> 32)[ran]
+    end_stream = ((t[:, 2] - t0).double() / 100.0)[ran]
+    spreads, firsts, lasts = [], [], []
+    for k in team.unique().tolist():
+        m = team == k
+        if int(m.sum()) > 1:
+            spreads.append(float(end_stream[m].max() - end_stream[m].min()))
+            firsts.append(float(end_stream[m].min()))
+            lasts.append(float(end_stream[m].max()))
+    if spreads:
+        sp = torch.tensor(spreads)
+        print(f"  within a (row, head group) team: streaming ends spread over median {sp.median():.2f} us, p90 {sp.quantile(0.9):.2f}, max {sp.max():.2f}; "
+              f"team's last end: median {torch.tensor(lasts).median():.2f} max {max(lasts):.2f}; mean of all ends {end_stream.mean():.2f}")
     hgs = (t[:, 6] >> 32)[ran]
     for h in sorted(set(hgs.tolist())):
         m = hgs == h
