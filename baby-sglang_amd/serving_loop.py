@@ -1,0 +1,311 @@
+"""Continuous batching over the paged pools with radix-cache prefix reuse.
+
+Behavioural counterpart of the reference's ``Scheduler.run_batch`` loop (reference:
+scheduler.py:107-168 loop, :242-301 prefill admission, :303-369 decode selection and
+retraction, :381-455 prefill batch, :457-507 decode batch, :553-587 result handling;
+radix_cache.py:141-207 caching of finished / running requests): the same admission
+policy, the same FIFO slot and row allocation, the same prefix-cache bookkeeping, so
+that an identical request stream produces identical ``SimplifiedForwardBatch``es --
+request rows, sequence lengths, ``out_cache_loc`` and page-table rows -- which is what
+the golden traces pin.
+
+What is arranged differently, for a GPU that should not wait on the host:
+  * every request keeps a host copy of its page-table row, so caching a request in the
+    prefix tree needs no device read;
+  * a decode step appends its new slots to the page table with one indexed device
+    write instead of one scalar write per request;
+  * greedy sampling is one ``argmax`` over the batch and one device-to-host copy per
+    step (the ids are needed on the host for finish checks and cache keys).
+"""
+
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from .forward_batch import SimplifiedForwardBatch
+from .memory_pool import MHATokenToKVPool, ReqToTokenPool
+from .prefix_cache import PrefixCache, PrefixNode
+
+
+@dataclass
+class SamplingParams:
+    """Fields of the reference's ``SamplingParams`` (sample.py:8-17)."""
+
+    max_new_tokens: int = 64
+    temperature: float = 1.0
+    top_k: int = 0
+    top_p: float = 1.0
+    eos_id: int = -1
+    do_sample: bool = False
+    repetition_penalty: float = 1.0
+
+
+@dataclass(eq=False)
+class Sequence_:
+    """One request in flight (counterpart of request.py:9-46)."""
+
+    input_ids: List[int]
+    max_new_tokens: int
+    eos_id: int
+    output_ids: List[int] = field(default_factory=list)
+    finished: bool = False
+    row: Optional[int] = None  # page-table row
+    seq_len: int = 0
+    table: List[int] = field(default_factory=list)  # host copy of the page-table row, seq_len entries
+    prefix_slots: torch.Tensor = field(default_factory=lambda: torch.empty(0, dtype=torch.int32))
+    last_node: Optional[PrefixNode] = None
+    num_cached: int = 0
+
+    def reset(self) -> None:
+        self.output_ids, self.finished, self.row, self.seq_len, self.table = [], False, None, 0, []
+        self.prefix_slots, self.last_node, self.num_cached = torch.empty(0, dtype=torch.int32), None, 0
+
+
+class ServingLoop:
+    def __init__(self, model, max_total_tokens: Optional[int] = None, max_requests: Optional[int] = None):
+        self.model = model
+        self.max_total_tokens = int(max_total_tokens or os.getenv("BABYSGL_MAX_TOTAL_TOKENS", "131072"))
+        self.max_requests = int(max_requests or os.getenv("BABYSGL_MAX_REQUESTS", "32"))
+        p = next(model.parameters())
+        self.device = p.device
+        cfg = model.config
+        self.req_to_token_pool = ReqToTokenPool(self.max_requests, self.max_total_tokens // self.max_requests, str(self.device))
+        self.token_to_kv_pool = MHATokenToKVPool(
+            self.max_total_tokens, p.dtype, cfg.num_key_value_heads, cfg.hidden_size // cfg.num_attention_heads,
+            cfg.num_hidden_layers, str(self.device),
+        )  # fmt: skip
+        self.tree_cache = PrefixCache()
+        # admission estimates (scheduler.py:63-69)
+        self.r_init, self.min_r = 0.5, 0.1
+        self.decay_step = (self.r_init - self.min_r) / 50
+        self.retract_decode_steps = 20
+        self.clip_max_new_tokens_estimation = 512
+        self.waiting: List[Sequence_] = []
+        self.decoding: List[Sequence_] = []
+        self.finished: List[Sequence_] = []
+        self.est_new_token_ratio = self.r_init
+        self.on_batch = None  # optional hook: on_batch(mode, forward_batch) before every model call
+
+    def reset(self) -> None:
+        self.req_to_token_pool.clear()
+        self.token_to_kv_pool.clear()
+        self.tree_cache.reset()
+        self.waiting, self.decoding, self.finished = [], [], []
+        self.est_new_token_ratio = self.r_init
+
+    # ---------------------------------------------------------------------------- the loop
+    def run_batch(self, requests: Sequence[torch.Tensor], sampling: Optional[SamplingParams] = None) -> List[List[int]]:
+        sampling = sampling or SamplingParams()
+        if sampling.do_sample or sampling.repetition_penalty > 1.0:
+            raise NotImplementedError("only greedy decoding is implemented in this driver")
+        self.waiting, self.decoding, self.finished = [], [], []
+        self.est_new_token_ratio = self.r_init
+        order = []
+        for ids in requests:
+            seq = Sequence_(input_ids=[int(t) for t in ids.tolist()],
+                            max_new_tokens=min(sampling.max_new_tokens, self.max_total_tokens), eos_id=sampling.eos_id)
+            self.waiting.append(seq)
+            order.append(seq)
+        while len(self.finished) < len(order):
+            batch, mode = self._select()
+            if mode == "error":
+                raise RuntimeError("Insufficient memory to process any requests")
+            fb = self._prefill_batch(batch) if mode == "prefill" else self._decode_batch(batch)
+            if self.on_batch is not None:
+                self.on_batch(mode, fb)
+            with torch.no_grad():
+                logits = self.model(fb.input_ids, fb.positions, fb)
+            self._finish_step(self._sample(logits, batch, mode), batch, mode)
+        return [s.output_ids for s in order]
+
+    # ---------------------------------------------------------------------------- selection
+    def _select(self) -> Tuple[List[Sequence_], str]:
+        if self.waiting:
+            admitted = self._admit_prefill()
+            if admitted:
+                return admitted, "prefill"
+        if self.decoding:
+            batch = self._select_decode()
+            if batch:
+                return batch, "decode"
+        return [], "error"
+
+    def _admit_prefill(self) -> List[Sequence_]:
+        tree = self.tree_cache
+        for s in self.waiting:
+            # never the whole prompt: at least one token must run through the model
+            s.prefix_slots, s.last_node = tree.match_prefix(s.input_ids[:-1])
+            s.num_cached = len(s.prefix_slots)
+        self.waiting.sort(key=lambda s: len(s.prefix_slots), reverse=True)
+        rows_free = self.req_to_token_pool.available_size()
+        reserved = sum(
+            min(int(self.est_new_token_ratio * (s.max_new_tokens - len(s.output_ids))), self.clip_max_new_tokens_estimation)
+            for s in self.decoding
+        )
+        budget = self.token_to_kv_pool.available_size() - reserved
+        admitted: List[Sequence_] = []
+        for s in self.waiting:
+            tree.inc_lock_ref(s.last_node)  # its own prefix does not count as evictable
+            need = len(s.input_ids) - len(s.prefix_slots) + s.max_new_tokens
+            fits = len(admitted) + 1 <= rows_free and need <= budget + tree.evictable_size()
+            if fits:
+                budget -= need
+                tree.inc_lock_ref(s.last_node)  # held while the request runs
+                admitted.append(s)
+            tree.dec_lock_ref(s.last_node)
+            if not fits:
+                break
+        return admitted
+
+    def _select_decode(self) -> List[Sequence_]:
+        pool, tree = self.token_to_kv_pool, self.tree_cache
+        bs = len(self.decoding)
+        if bs > pool.available_size():
+            tree.evict(bs, pool.free)
+        if bs <= pool.available_size():
+            self.est_new_token_ratio = max(self.min_r, self.est_new_token_ratio - self.decay_step)
+            return list(self.decoding)
+        # still short: send the newest requests back to the queue (scheduler.py:322-369)
+        while len(self.decoding) * self.retract_decode_steps > pool.available_size():
+            if not self.decoding:
+                break
+            s = self.decoding.pop()
+            pool.free(torch.tensor(s.table[s.num_cached : s.seq_len], dtype=torch.int32))
+            self.req_to_token_pool.free(s.row)
+            tree.dec_lock_ref(s.last_node)
+            s.reset()
+            self.waiting.append(s)
+            short = max(0, len(self.decoding) * self.retract_decode_steps - pool.available_size())
+            if short > 0:
+                tree.evict(short, pool.free)
+        assert self.decoding
+        done = sum(len(s.output_ids) for s in self.decoding)
+        cap = sum(s.max_new_tokens for s in self.decoding)
+        self.est_new_token_ratio = min(1.0, (done + len(self.decoding) * self.retract_decode_steps) / cap)
+        return list(self.decoding)
+
+    # ---------------------------------------------------------------------------- batches
+    def _alloc_slots(self, n: int) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+        """(host copy, device tensor) of the next n free slots, or (None, None)."""
+        pool = self.token_to_kv_pool
+        if n > pool.available_size():
+            return None, None
+        host = pool.free_slots[:n].clone()
+        return host, pool.alloc(n)
+
+    def _prefill_batch(self, batch: List[Sequence_]) -> SimplifiedForwardBatch:
+        r2t = self.req_to_token_pool
+        rows = r2t.alloc(len(batch))
+        if rows is None:
+            raise RuntimeError("Failed to allocate request pool indices")
+        new_ids = [t for s in batch for t in s.input_ids[s.num_cached :]]
+        host_loc, out_cache_loc = self._alloc_slots(len(new_ids))
+        if host_loc is None:
+            self.tree_cache.evict(len(new_ids), self.token_to_kv_pool.free)
+            host_loc, out_cache_loc = self._alloc_slots(len(new_ids))
+            if host_loc is None:
+                avail = self.token_to_kv_pool.available_size() + self.tree_cache.evictable_size()
+                raise RuntimeError(f"Prefill OOM: need {len(new_ids)}, available {avail}")
+        mapping = torch.zeros((len(batch), r2t.max_context_len), dtype=torch.int32)
+        used = 0
+        for i, s in enumerate(batch):
+            n_new = len(s.input_ids) - s.num_cached
+            s.row, s.seq_len = rows[i], len(s.input_ids)
+            s.table = s.prefix_slots.tolist() + host_loc[used : used + n_new].tolist()
+            mapping[i, : s.seq_len] = torch.tensor(s.table, dtype=torch.int32)
+            used += n_new
+        dev = self.device
+        rows_t = torch.tensor(rows, dtype=torch.long, device=dev)
+        r2t.write(rows_t, mapping.to(dev))
+        return SimplifiedForwardBatch.create_prefill_batch(
+            input_ids=torch.tensor(new_ids, dtype=torch.long, device=dev),
+            req_pool_indices=rows_t,
+            seq_lens=torch.tensor([s.seq_len for s in batch], dtype=torch.long, device=dev),
+            out_cache_loc=out_cache_loc,
+            req_to_token_pool=r2t,
+            token_to_kv_pool=self.token_to_kv_pool,
+            prefix_lens=torch.tensor([s.num_cached for s in batch], dtype=torch.long, device=dev),
+        )
+
+    def _decode_batch(self, batch: List[Sequence_]) -> SimplifiedForwardBatch:
+        host_loc, new_slots = self._alloc_slots(len(batch))
+        if host_loc is None:
+            raise RuntimeError("Failed to allocate KV slots for decode")
+        for s, slot in zip(batch, host_loc.tolist()):
+            if s.row is None or not s.output_ids:
+                raise RuntimeError("request scheduled for decode without a page-table row or a token to feed")
+            s.table.append(slot)  # position seq_len
+            s.seq_len += 1
+        dev = self.device
+        rows_t = torch.tensor([s.row for s in batch], dtype=torch.long, device=dev)
+        seq_t = torch.tensor([s.seq_len for s in batch], dtype=torch.long, device=dev)
+        # one indexed write appends every request's new slot to its page-table row
+        self.req_to_token_pool.req_to_token[rows_t, seq_t - 1] = new_slots
+        return SimplifiedForwardBatch.create_decode_batch(
+            input_ids=torch.tensor([s.output_ids[-1] for s in batch], dtype=torch.long, device=dev),
+            req_pool_indices=rows_t,
+            seq_lens=seq_t,
+            out_cache_loc=new_slots,
+            req_to_token_pool=self.req_to_token_pool,
+            token_to_kv_pool=self.token_to_kv_pool,
+        )
+
+    # ---------------------------------------------------------------------------- results
+    def _sample(self, logits: torch.Tensor, batch: List[Sequence_], mode: str) -> List[int]:
+        if mode == "prefill":  # the last new token of each request predicts its first output
+            ends = torch.cumsum(torch.tensor([len(s.input_ids) - s.num_cached for s in batch]), dim=0) - 1
+            logits = logits[ends.to(logits.device)]
+        return torch.argmax(logits, dim=-1).tolist()
+
+    def _finish_step(self, next_ids: List[int], batch: List[Sequence_], mode: str) -> None:
+        for s, tok in zip(batch, next_ids):
+            s.output_ids.append(int(tok))
+            s.finished = len(s.output_ids) >= s.max_new_tokens or (s.eos_id != -1 and tok == s.eos_id)
+        for s in batch:
+            if s.finished:
+                self._cache_finished(s)
+                self.finished.append(s)
+            elif mode == "prefill":
+                self._cache_running(s)
+                self.decoding.append(s)
+            if mode == "prefill" and s in self.waiting:
+                self.waiting.remove(s)
+        if mode == "decode":
+            self.decoding = [s for s in self.decoding if not s.finished]
+
+    def _cache_finished(self, s: Sequence_) -> None:
+        """radix_cache.py:141-173: the tokens whose K/V are written (all but the last
+        generated one) go into the tree; duplicates of already cached slots are freed."""
+        tokens = (s.input_ids + s.output_ids)[:-1] if s.output_ids else list(s.input_ids)
+        if tokens:
+            slots = torch.tensor(s.table[: len(tokens)], dtype=torch.int32)
+            had = self.tree_cache.insert(tokens, slots)
+            if had > len(s.prefix_slots):
+                self.token_to_kv_pool.free(slots[len(s.prefix_slots) : had])
+        self.req_to_token_pool.free(s.row)
+        self.tree_cache.dec_lock_ref(s.last_node)
+
+    def _cache_running(self, s: Sequence_) -> None:
+        """radix_cache.py:175-207: cache the prompt of a request that goes on decoding
+        and point its page-table row at the tree's own slots for it."""
+        tokens = list(s.input_ids)
+        if not tokens:
+            return
+        tree = self.tree_cache
+        slots = torch.tensor(s.table[: len(tokens)], dtype=torch.int32)
+        had = tree.insert(tokens, slots)
+        n_old = len(s.prefix_slots)
+        if had > n_old:
+            self.token_to_kv_pool.free(slots[n_old:had])
+        canon, node = tree.match_prefix(tokens)
+        assert len(canon) == len(tokens)
+        if len(canon) > n_old:
+            s.table[n_old : len(canon)] = canon[n_old:].tolist()
+            self.req_to_token_pool.write((s.row, slice(n_old, len(canon))), canon[n_old:].to(self.device))
+        tree.dec_lock_ref(s.last_node)
+        tree.inc_lock_ref(node)
+        s.prefix_slots, s.last_node = canon, node

@@ -1,0 +1,112 @@
+"""The serving loop against traces of the reference scheduler (CPU only).
+
+``tests/golden/driver_traces.pt`` records every model call the reference
+``Scheduler.run_batch`` made for four request streams driven by a stand-in model whose
+logits depend only on (token id, position).  The same streams through
+``ServingLoop`` must give the same calls -- mode, input ids, positions, request rows,
+sequence lengths, new slots, prefix lengths and page-table rows, bit for bit -- and the
+same output ids.  The prefix tree is also exercised directly."""
+import types
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from conftest import load_golden
+from baby_sglang_amd.prefix_cache import PrefixCache
+from baby_sglang_amd.serving_loop import SamplingParams, ServingLoop
+
+TRACES = load_golden("driver_traces")
+
+
+class StandInModel(nn.Module):
+    """Same function as the one the goldens were generated with."""
+
+    def __init__(self, vocab):
+        super().__init__()
+        self.config = types.SimpleNamespace(num_key_value_heads=1, hidden_size=64, num_attention_heads=1,
+                                            num_hidden_layers=1, vocab_size=vocab)
+        self.dummy = nn.Parameter(torch.zeros(1))
+
+    def forward(self, input_ids, positions, forward_batch, input_embeds=None):
+        return F.one_hot((7 * input_ids + 3 * positions + 1) % self.config.vocab_size, self.config.vocab_size).float()
+
+
+@pytest.mark.parametrize("name", sorted(TRACES["scenarios"]))
+def test_same_batches_as_the_reference_scheduler(name):
+    sc = TRACES["scenarios"][name]
+    loop = ServingLoop(StandInModel(TRACES["vocab"]), max_total_tokens=sc["max_total_tokens"], max_requests=sc["max_requests"])
+    seen = []
+
+    def record(mode, fb):
+        seen.append({
+            "mode": mode, "input_ids": fb.input_ids.clone(), "positions": fb.positions.clone(),
+            "req_pool_indices": fb.req_pool_indices.clone(), "seq_lens": fb.seq_lens.clone(),
+            "out_cache_loc": fb.out_cache_loc.clone(),
+            "prefix_lens": None if fb.prefix_lens is None else fb.prefix_lens.clone(),
+            "table_rows": fb.req_to_token_pool.req_to_token[fb.req_pool_indices].clone(),
+        })  # fmt: skip
+
+    loop.on_batch = record
+    outs = loop.run_batch(sc["prompts"], SamplingParams(max_new_tokens=sc["max_new_tokens"], eos_id=sc["eos_id"]))
+    assert [list(o) for o in outs] == [o.tolist() for o in sc["output_ids"]]
+    assert len(seen) == len(sc["steps"])
+    for i, (got, want) in enumerate(zip(seen, sc["steps"])):
+        assert got["mode"] == want["mode"], i
+        for key in ("input_ids", "positions", "req_pool_indices", "seq_lens", "out_cache_loc", "prefix_lens", "table_rows"):
+            if want[key] is None:
+                assert got[key] is None, (i, key)
+            else:
+                assert torch.equal(got[key].to(want[key].dtype), want[key]), (i, key)
+    if name == "eviction":
+        assert sc["counts"]["evict"] > 0  # the trace really went through eviction
+    # everything went back: rows free, slots free or owned by the tree
+    assert loop.req_to_token_pool.available_size() == sc["max_requests"]
+    assert loop.token_to_kv_pool.available_size() + loop.tree_cache.evictable_size() == sc["max_total_tokens"]
+    # a second run on the same loop reuses what the tree kept
+    outs2 = loop.run_batch(sc["prompts"], SamplingParams(max_new_tokens=sc["max_new_tokens"], eos_id=sc["eos_id"]))
+    assert [list(o) for o in outs2] == [o.tolist() for o in sc["output_ids"]]
+
+
+def test_prefix_tree_split_insert_lock_evict():
+    tree = PrefixCache()
+    freed = []
+    a = torch.arange(10, 16, dtype=torch.int32)
+    assert tree.insert([1, 2, 3, 4, 5, 6], a) == 0
+    assert tree.evictable_size() == 6
+    # a key that leaves the cached one after three tokens: the node splits, three slots match
+    slots, node = tree.match_prefix([1, 2, 3, 9, 9])
+    assert slots.tolist() == [10, 11, 12] and node.key == [1, 2, 3]
+    assert [c.key for c in node.children.values()] == [[4, 5, 6]]
+    # inserting the diverging key reports the three tokens already present
+    b = torch.arange(20, 25, dtype=torch.int32)
+    assert tree.insert([1, 2, 3, 9, 9], b) == 3
+    assert tree.evictable_size() == 8  # 3 shared + 3 + 2
+    # lock one branch: its nodes (and the shared head) leave the evictable count
+    _, leaf = tree.match_prefix([1, 2, 3, 4, 5, 6])
+    tree.inc_lock_ref(leaf)
+    assert tree.evictable_size() == 2
+    tree.evict(100, lambda s: freed.extend(s.tolist()))
+    assert freed == [23, 24]  # only the unlocked leaf went; its parent still has a child
+    tree.dec_lock_ref(leaf)
+    tree.evict(100, lambda s: freed.extend(s.tolist()))
+    assert sorted(freed) == [10, 11, 12, 13, 14, 15, 23, 24] and tree.evictable_size() == 0
+    assert tree.match_prefix([1, 2, 3])[0].numel() == 0
+
+
+def test_least_recently_used_leaf_goes_first():
+    tree = PrefixCache()
+    tree.insert([1, 1], torch.tensor([1, 2], dtype=torch.int32))
+    tree.insert([2, 2], torch.tensor([3, 4], dtype=torch.int32))
+    tree.insert([3, 3], torch.tensor([5, 6], dtype=torch.int32))
+    tree.match_prefix([1, 1])  # touch the oldest
+    freed = []
+    tree.evict(2, lambda s: freed.extend(s.tolist()))
+    assert freed == [3, 4]
+
+
+def test_only_greedy_is_implemented():
+    loop = ServingLoop(StandInModel(11), max_total_tokens=64, max_requests=2)
+    with pytest.raises(NotImplementedError):
+        loop.run_batch([torch.tensor([1, 2, 3])], SamplingParams(do_sample=True))
