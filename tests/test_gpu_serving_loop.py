@@ -1,0 +1,77 @@
+"""The serving loop on the GPU: continuous batching + prefix reuse over the HIP path.
+
+``tests/golden/driver_traces.pt`` (``tiny_model_e2e``) holds what the reference
+``Scheduler.run_batch`` did with the tiny random-weight reference model on five prompts
+that share a prefix, three page-table rows (two admission waves), fp32 on the CPU:
+every model call's batch and the greedy output ids.  ``ServingLoop`` over the HIP-path
+model with the same weights must make the same calls and produce the same ids, and a
+second run on the same loop, which now finds every prompt in the prefix tree, too.
+"""
+import types
+
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _tiny_model(dev, dtype=torch.float32):
+    import baby_sglang_amd as pkg
+
+    g = load_golden("tiny_model")
+    cfg = types.SimpleNamespace(**g["config"], tie_word_embeddings=False, hidden_act="silu", rope_scaling=None)
+    model = pkg.BabyQwen2ForCausalLM(cfg).eval()
+    model.load_state_dict(g["state_dict"], strict=True)
+    return model.to(dtype).to(dev)
+
+
+def test_tiny_model_end_to_end_matches_reference_scheduler(gpu):
+    from baby_sglang_amd.serving_loop import SamplingParams, ServingLoop
+
+    e2e = load_golden("driver_traces")["tiny_model_e2e"]
+    loop = ServingLoop(_tiny_model(gpu), max_total_tokens=e2e["max_total_tokens"], max_requests=e2e["max_requests"])
+    seen = []
+    loop.on_batch = lambda mode, fb: seen.append((mode, fb))
+    sp = SamplingParams(max_new_tokens=e2e["max_new_tokens"], eos_id=e2e["eos_id"])
+    outs = loop.run_batch(e2e["prompts"], sp)
+    assert [list(o) for o in outs] == [o.tolist() for o in e2e["output_ids"]]
+    assert len(seen) == len(e2e["steps"])
+    for i, ((mode, fb), want) in enumerate(zip(seen, e2e["steps"])):
+        assert mode == want["mode"], i
+        for key in ("input_ids", "positions", "req_pool_indices", "seq_lens", "out_cache_loc", "prefix_lens"):
+            got = getattr(fb, key)
+            if want[key] is None:
+                assert got is None, (i, key)
+            else:
+                assert torch.equal(got.cpu().to(want[key].dtype), want[key]), (i, key)
+    # second pass: the prompts are in the prefix tree now, so prefill runs over one token each
+    seen.clear()
+    outs2 = loop.run_batch(e2e["prompts"], sp)
+    assert [list(o) for o in outs2] == [o.tolist() for o in e2e["output_ids"]]
+    first_prefill = next(fb for mode, fb in seen if mode == "prefill")
+    assert int(first_prefill.extended_lens.max()) == 1
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batch_of_shared_prefixes(gpu, dtype):
+    """More requests than page-table rows, a long shared prefix: two fresh loops give the
+    same ids (both dtypes); in fp32 the ids do not depend on whether a request ran alone
+    (whole prompt through prefill) or batched behind a cached prefix (extend + batched decode)."""
+    from baby_sglang_amd.serving_loop import SamplingParams, ServingLoop
+
+    model = _tiny_model(gpu, dtype)
+    vocab = model.config.vocab_size
+    gen = torch.Generator().manual_seed(5)
+    shared = torch.randint(0, vocab, (40,), generator=gen)
+    prompts = [torch.cat([shared, torch.randint(0, vocab, (n,), generator=gen)]) for n in (3, 9, 1, 17, 6, 2, 11)]
+    sp = SamplingParams(max_new_tokens=8)
+    a = ServingLoop(model, max_total_tokens=512, max_requests=4).run_batch(prompts, sp)
+    b = ServingLoop(model, max_total_tokens=512, max_requests=4).run_batch(prompts, sp)
+    assert a == b
+    assert all(len(o) == 8 for o in a)
+    if dtype == torch.float32:
+        for i in (0, 3, 6):
+            alone = ServingLoop(model, max_total_tokens=512, max_requests=4).run_batch([prompts[i]], sp)
+            assert alone[0] == a[i], i
