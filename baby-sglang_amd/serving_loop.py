@@ -16,6 +16,15 @@ What is arranged differently, for a GPU that should not wait on the host:
     write instead of one scalar write per request;
   * greedy sampling is one ``argmax`` over the batch and one device-to-host copy per
     step (the ids are needed on the host for finish checks and cache keys).
+
+Chunked prefill (not in the reference, whose scheduler admits whole prompts,
+scheduler.py:286-299, although its backend's extend semantics allow it,
+attn_backend.py:43-59): with ``chunked_prefill_size = N`` an admitted prefill batch of
+more than N new tokens goes through the model as several extend calls of at most N
+tokens each.  Admission, slots and page-table rows are exactly those of the unchunked
+batch -- every row is written up front -- and a chunk is an extend over
+``prefix_len + tokens already run``; a request cut by a chunk border continues in the
+next call, and a request is sampled from the call that holds its last prompt token.
 """
 
 from __future__ import annotations
@@ -66,8 +75,12 @@ class Sequence_:
 
 
 class ServingLoop:
-    def __init__(self, model, max_total_tokens: Optional[int] = None, max_requests: Optional[int] = None):
+    def __init__(self, model, max_total_tokens: Optional[int] = None, max_requests: Optional[int] = None,
+                 chunked_prefill_size: Optional[int] = None):
         self.model = model
+        if chunked_prefill_size is not None and chunked_prefill_size < 1:
+            raise ValueError("chunked_prefill_size must be positive")
+        self.chunked_prefill_size = chunked_prefill_size
         self.max_total_tokens = int(max_total_tokens or os.getenv("BABYSGL_MAX_TOTAL_TOKENS", "131072"))
         self.max_requests = int(max_requests or os.getenv("BABYSGL_MAX_REQUESTS", "32"))
         p = next(model.parameters())
@@ -114,13 +127,66 @@ class ServingLoop:
             batch, mode = self._select()
             if mode == "error":
                 raise RuntimeError("Insufficient memory to process any requests")
-            fb = self._prefill_batch(batch) if mode == "prefill" else self._decode_batch(batch)
-            if self.on_batch is not None:
-                self.on_batch(mode, fb)
-            with torch.no_grad():
-                logits = self.model(fb.input_ids, fb.positions, fb)
-            self._finish_step(self._sample(logits, batch, mode), batch, mode)
+            if mode == "prefill":
+                next_ids = self._run_prefill(batch)
+            else:
+                fb = self._decode_batch(batch)
+                next_ids = torch.argmax(self._forward(mode, fb), dim=-1).tolist()
+            self._finish_step(next_ids, batch, mode)
         return [s.output_ids for s in order]
+
+    def _forward(self, mode: str, fb: SimplifiedForwardBatch) -> torch.Tensor:
+        if self.on_batch is not None:
+            self.on_batch(mode, fb)
+        with torch.no_grad():
+            return self.model(fb.input_ids, fb.positions, fb)
+
+    def _run_prefill(self, batch: List[Sequence_]) -> List[int]:
+        """The admitted batch through the model, whole or in chunks; the token each
+        request's last prompt position predicts."""
+        fb = self._prefill_batch(batch)
+        n_new = [len(s.input_ids) - s.num_cached for s in batch]
+        limit = self.chunked_prefill_size
+        if limit is None or sum(n_new) <= limit:
+            ends = torch.cumsum(torch.tensor(n_new), dim=0) - 1
+            return torch.argmax(self._forward("prefill", fb)[ends.to(self.device)], dim=-1).tolist()
+        next_ids: List[Optional[int]] = [None] * len(batch)
+        first = [0]
+        for n in n_new:
+            first.append(first[-1] + n)  # offset of each request's new tokens in the batch's token list
+        done = [0] * len(batch)  # new tokens of each request already run
+        i = 0
+        while i < len(batch):
+            room, members = limit, []  # (request index, tokens taken)
+            j = i
+            while j < len(batch) and room > 0:
+                take = min(room, n_new[j] - done[j])
+                members.append((j, take))
+                room -= take
+                if done[j] + take < n_new[j]:
+                    break  # cut by the chunk border: continues in the next call
+                j += 1
+            tok = torch.cat([torch.arange(first[m] + done[m], first[m] + done[m] + t) for m, t in members]).to(self.device)
+            idx = torch.tensor([m for m, _ in members], device=self.device)
+            prefix = torch.tensor([batch[m].num_cached + done[m] for m, _ in members], dtype=torch.long, device=self.device)
+            takes = torch.tensor([t for _, t in members], dtype=torch.long, device=self.device)
+            chunk = SimplifiedForwardBatch.create_prefill_batch(
+                input_ids=fb.input_ids[tok], req_pool_indices=fb.req_pool_indices[idx], seq_lens=prefix + takes,
+                out_cache_loc=fb.out_cache_loc[tok], req_to_token_pool=fb.req_to_token_pool,
+                token_to_kv_pool=fb.token_to_kv_pool, prefix_lens=prefix,
+            )  # fmt: skip
+            logits = self._forward("prefill", chunk)
+            ends = (torch.cumsum(takes, dim=0) - 1).tolist()
+            finished = [(m, e) for (m, t), e in zip(members, ends) if done[m] + t == n_new[m]]
+            if finished:
+                rows = torch.tensor([e for _, e in finished], device=self.device)
+                for (m, _), tok_id in zip(finished, torch.argmax(logits[rows], dim=-1).tolist()):
+                    next_ids[m] = tok_id
+            for m, t in members:
+                done[m] += t
+            while i < len(batch) and done[i] == n_new[i]:
+                i += 1
+        return next_ids
 
     # ---------------------------------------------------------------------------- selection
     def _select(self) -> Tuple[List[Sequence_], str]:
@@ -255,12 +321,6 @@ class ServingLoop:
         )
 
     # ---------------------------------------------------------------------------- results
-    def _sample(self, logits: torch.Tensor, batch: List[Sequence_], mode: str) -> List[int]:
-        if mode == "prefill":  # the last new token of each request predicts its first output
-            ends = torch.cumsum(torch.tensor([len(s.input_ids) - s.num_cached for s in batch]), dim=0) - 1
-            logits = logits[ends.to(logits.device)]
-        return torch.argmax(logits, dim=-1).tolist()
-
     def _finish_step(self, next_ids: List[int], batch: List[Sequence_], mode: str) -> None:
         for s, tok in zip(batch, next_ids):
             s.output_ids.append(int(tok))

@@ -75,3 +75,19 @@ def test_batch_of_shared_prefixes(gpu, dtype):
         for i in (0, 3, 6):
             alone = ServingLoop(model, max_total_tokens=512, max_requests=4).run_batch([prompts[i]], sp)
             assert alone[0] == a[i], i
+
+
+@pytest.mark.parametrize("limit", [5, 16])
+def test_chunked_prefill_gives_the_reference_ids(gpu, limit):
+    """Prompts run through the model as extend calls of at most ``limit`` tokens (each over
+    what the earlier calls cached): the ids are those of the reference's whole-prompt prefill."""
+    from baby_sglang_amd.serving_loop import SamplingParams, ServingLoop
+
+    e2e = load_golden("driver_traces")["tiny_model_e2e"]
+    loop = ServingLoop(_tiny_model(gpu), max_total_tokens=e2e["max_total_tokens"], max_requests=e2e["max_requests"],
+                       chunked_prefill_size=limit)
+    sizes = []
+    loop.on_batch = lambda mode, fb: sizes.append(len(fb.input_ids)) if mode == "prefill" else None
+    outs = loop.run_batch(e2e["prompts"], SamplingParams(max_new_tokens=e2e["max_new_tokens"], eos_id=e2e["eos_id"]))
+    assert [list(o) for o in outs] == [o.tolist() for o in e2e["output_ids"]]
+    assert max(sizes) <= limit and len(sizes) > sum(1 for s in e2e["steps"] if s["mode"] == "prefill")

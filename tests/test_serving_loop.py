@@ -69,6 +69,47 @@ def test_same_batches_as_the_reference_scheduler(name):
     assert [list(o) for o in outs2] == [o.tolist() for o in sc["output_ids"]]
 
 
+@pytest.mark.parametrize("name", sorted(TRACES["scenarios"]))
+@pytest.mark.parametrize("limit", [1, 7, 16])
+def test_chunked_prefill_makes_the_same_decisions(name, limit):
+    """Prefill batches cut into extend calls of at most ``limit`` tokens: same output ids,
+    same decode calls, and the chunks of a prefill batch put together are that batch."""
+    sc = TRACES["scenarios"][name]
+    loop = ServingLoop(StandInModel(TRACES["vocab"]), max_total_tokens=sc["max_total_tokens"],
+                       max_requests=sc["max_requests"], chunked_prefill_size=limit)
+    calls = []
+    loop.on_batch = lambda mode, fb: calls.append((mode, fb))
+    outs = loop.run_batch(sc["prompts"], SamplingParams(max_new_tokens=sc["max_new_tokens"], eos_id=sc["eos_id"]))
+    assert [list(o) for o in outs] == [o.tolist() for o in sc["output_ids"]]
+    i = 0
+    for want in sc["steps"]:
+        if want["mode"] == "decode":
+            mode, fb = calls[i]
+            i += 1
+            assert mode == "decode" and torch.equal(fb.out_cache_loc, want["out_cache_loc"]) and torch.equal(fb.seq_lens, want["seq_lens"])
+            continue
+        parts, n_tok = [], 0
+        while n_tok < len(want["input_ids"]):
+            mode, fb = calls[i]
+            i += 1
+            assert mode == "prefill" and 0 < len(fb.input_ids) <= limit
+            assert int(fb.extended_lens.sum()) == len(fb.input_ids) and bool((fb.seq_lens == fb.prefix_lens + fb.extended_lens).all())
+            parts.append(fb)
+            n_tok += len(fb.input_ids)
+        for key in ("input_ids", "positions", "out_cache_loc"):
+            assert torch.equal(torch.cat([getattr(fb, key) for fb in parts]), want[key]), key
+        # every request of the batch appears, in order; one cut by a border appears in consecutive calls
+        rows = torch.cat([fb.req_pool_indices for fb in parts]).tolist()
+        assert [r for k, r in enumerate(rows) if k == 0 or rows[k - 1] != r] == want["req_pool_indices"].tolist()
+        # a request's last chunk ends at its full length
+        last_len = {}
+        for fb in parts:
+            for r, n in zip(fb.req_pool_indices.tolist(), fb.seq_lens.tolist()):
+                last_len[r] = n
+        assert [last_len[r] for r in want["req_pool_indices"].tolist()] == want["seq_lens"].tolist()
+    assert i == len(calls)
+
+
 def test_prefix_tree_split_insert_lock_evict():
     tree = PrefixCache()
     freed = []
