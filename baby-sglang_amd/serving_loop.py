@@ -74,6 +74,28 @@ class Sequence_:
         self.prefix_slots, self.last_node, self.num_cached = torch.empty(0, dtype=torch.int32), None, 0
 
 
+def chunk_members(n_new: Sequence[int], limit: int):
+    """Cut a batch whose request i brings ``n_new[i]`` tokens into calls of at most
+    ``limit`` tokens: yields, per call, ``[(request index, tokens taken), ...]`` in batch
+    order; a request cut by a call's border continues at the head of the next call."""
+    done = [0] * len(n_new)
+    i = 0
+    while i < len(n_new):
+        room, members = limit, []
+        j = i
+        while j < len(n_new) and room > 0:
+            take = min(room, n_new[j] - done[j])
+            members.append((j, take))
+            room -= take
+            done[j] += take
+            if done[j] < n_new[j]:
+                break
+            j += 1
+        while i < len(n_new) and done[i] == n_new[i]:
+            i += 1
+        yield members
+
+
 class ServingLoop:
     def __init__(self, model, max_total_tokens: Optional[int] = None, max_requests: Optional[int] = None,
                  chunked_prefill_size: Optional[int] = None):
@@ -155,17 +177,7 @@ class ServingLoop:
         for n in n_new:
             first.append(first[-1] + n)  # offset of each request's new tokens in the batch's token list
         done = [0] * len(batch)  # new tokens of each request already run
-        i = 0
-        while i < len(batch):
-            room, members = limit, []  # (request index, tokens taken)
-            j = i
-            while j < len(batch) and room > 0:
-                take = min(room, n_new[j] - done[j])
-                members.append((j, take))
-                room -= take
-                if done[j] + take < n_new[j]:
-                    break  # cut by the chunk border: continues in the next call
-                j += 1
+        for members in chunk_members(n_new, limit):
             tok = torch.cat([torch.arange(first[m] + done[m], first[m] + done[m] + t) for m, t in members]).to(self.device)
             idx = torch.tensor([m for m, _ in members], device=self.device)
             prefix = torch.tensor([batch[m].num_cached + done[m] for m, _ in members], dtype=torch.long, device=self.device)
@@ -184,8 +196,6 @@ class ServingLoop:
                     next_ids[m] = tok_id
             for m, t in members:
                 done[m] += t
-            while i < len(batch) and done[i] == n_new[i]:
-                i += 1
         return next_ids
 
     # ---------------------------------------------------------------------------- selection
