@@ -56,7 +56,8 @@ class SimplifiedForwardBatch:
         device = input_ids.device
         extended_lens = (seq_lens - prefix_lens).to(dtype=torch.long, device=device)
         starts = prefix_lens.to(dtype=torch.long, device=device)
-        total = int(extended_lens.sum().item()) if extended_lens.numel() else 0
+        # (the batch carries exactly its requests' extend tokens: no device read needed for the total)
+        total = int(input_ids.shape[0])
         owner = torch.repeat_interleave(
             torch.arange(len(req_pool_indices), device=device),
             extended_lens,

@@ -196,7 +196,15 @@ class BabyQwen2ForCausalLM(nn.Module):
         else:
             self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
 
+    supports_logits_rows = True
+
     @torch.no_grad()
-    def forward(self, input_ids, positions, forward_batch, input_embeds=None):
+    def forward(self, input_ids, positions, forward_batch, input_embeds=None, logits_rows=None):
+        """Logits ``[T, vocab]`` of every input token (qwen2.py:21-37), or, with
+        ``logits_rows`` (token indices), of those tokens only: a prefill batch is sampled
+        from the last token of each request, and the other rows of the vocabulary projection
+        are most of the work and memory of a long prompt."""
         hidden_states = self.model(input_ids, positions, forward_batch, input_embeds)
+        if logits_rows is not None:
+            hidden_states = hidden_states[logits_rows]
         return F.linear(hidden_states, self.lm_head.weight)

@@ -17,6 +17,19 @@ What is arranged differently, for a GPU that should not wait on the host:
   * greedy sampling is one ``argmax`` over the batch and one device-to-host copy per
     step (the ids are needed on the host for finish checks and cache keys).
 
+Overlap mode (``run_batch_overlap``; reference: scheduler.py:599-761 with
+overlap_worker.py:27-160): the next batch is selected, built and launched while the
+previous one is still running, and a batch's sampled ids are looked at one step late.
+The reference does this with a worker thread on a second stream and negative
+placeholder ids resolved from a "future token" map; here one thread and one HIP stream
+do: sampled ids stay on the device in a per-row buffer that the next decode batch
+gathers its input ids from, every host-to-device copy of batch metadata goes through
+pinned staging memory without blocking, and the only wait of a step is on the event
+behind the PREVIOUS step's device-to-host copy of its ids.  As in the reference, a
+request that stops on its eos token is found out a step late, so it runs one decode step
+too many whose slot is handed back (scheduler.py:740-746); a request that stops on its
+token budget is not scheduled again, the count of tokens in flight being known.
+
 Chunked prefill (not in the reference, whose scheduler admits whole prompts,
 scheduler.py:286-299, although its backend's extend semantics allow it,
 attn_backend.py:43-59): with ``chunked_prefill_size = N`` an admitted prefill batch of
@@ -68,6 +81,7 @@ class Sequence_:
     prefix_slots: torch.Tensor = field(default_factory=lambda: torch.empty(0, dtype=torch.int32))
     last_node: Optional[PrefixNode] = None
     num_cached: int = 0
+    in_flight: int = 0  # steps launched whose ids have not been looked at yet (overlap mode)
 
     def reset(self) -> None:
         self.output_ids, self.finished, self.row, self.seq_len, self.table = [], False, None, 0, []
@@ -124,6 +138,13 @@ class ServingLoop:
         self.finished: List[Sequence_] = []
         self.est_new_token_ratio = self.r_init
         self.on_batch = None  # optional hook: on_batch(mode, forward_batch) before every model call
+        # pinned staging for host-to-device copies that must not block (three arenas in rotation:
+        # one per step being built, in flight, and just finished)
+        self._staging = None
+        self._staging_turn = 0
+        self._staging_used = 0
+        self._last_ids = None  # device: the id each page-table row's request produced last
+        self._ids_host = None  # pinned landing buffers of the per-step id copies, in the same rotation
 
     def reset(self) -> None:
         self.req_to_token_pool.clear()
@@ -131,6 +152,32 @@ class ServingLoop:
         self.tree_cache.reset()
         self.waiting, self.decoding, self.finished = [], [], []
         self.est_new_token_ratio = self.r_init
+
+    # ---------------------------------------------------------------------------- copies
+    def _next_staging(self) -> None:
+        if self.device.type != "cuda":
+            return
+        if self._staging is None:
+            n = self.max_requests * self.req_to_token_pool.max_context_len // 2 + (1 << 16)
+            self._staging = [torch.empty(n, dtype=torch.int64).pin_memory() for _ in range(3)]
+        self._staging_turn = (self._staging_turn + 1) % 3
+        self._staging_used = 0
+
+    def _h2d(self, data, dtype: torch.dtype) -> torch.Tensor:
+        """``data`` (list or CPU tensor) as a device tensor of ``dtype``, without making the
+        host wait for the stream: through this step's pinned arena when it fits."""
+        t = data.to(dtype) if isinstance(data, torch.Tensor) else torch.tensor(data, dtype=dtype)
+        if self.device.type != "cuda":
+            return t.to(self.device)
+        n64 = (t.numel() * t.element_size() + 7) // 8
+        if self._staging is None or self._staging_used + n64 > self._staging[0].numel():
+            return t.to(self.device)  # (blocking copy: correct, only slower)
+        arena = self._staging[self._staging_turn]
+        stage = arena[self._staging_used : self._staging_used + n64].view(torch.uint8)[: t.numel() * t.element_size()]
+        stage = stage.view(dtype).view(t.shape)
+        stage.copy_(t)
+        self._staging_used += n64
+        return stage.to(self.device, non_blocking=True)
 
     # ---------------------------------------------------------------------------- the loop
     def run_batch(self, requests: Sequence[torch.Tensor], sampling: Optional[SamplingParams] = None) -> List[List[int]]:
@@ -157,11 +204,126 @@ class ServingLoop:
             self._finish_step(next_ids, batch, mode)
         return [s.output_ids for s in order]
 
-    def _forward(self, mode: str, fb: SimplifiedForwardBatch) -> torch.Tensor:
+    def run_batch_overlap(self, requests: Sequence[torch.Tensor], sampling: Optional[SamplingParams] = None) -> List[List[int]]:
+        """``run_batch`` with a batch's ids looked at one step late, so that selecting,
+        building and launching the next batch overlaps the current one on the GPU.  Same
+        output ids as ``run_batch``."""
+        sampling = sampling or SamplingParams()
+        if sampling.do_sample or sampling.repetition_penalty > 1.0:
+            raise NotImplementedError("only greedy decoding is implemented in this driver")
+        if self.chunked_prefill_size is not None:
+            raise NotImplementedError("overlap mode runs whole-prompt prefill batches")
+        self.waiting, self.decoding, self.finished = [], [], []
+        self.est_new_token_ratio = self.r_init
+        if self._last_ids is None:
+            self._last_ids = torch.zeros(self.max_requests, dtype=torch.long, device=self.device)
+        order = []
+        for ids in requests:
+            seq = Sequence_(input_ids=[int(t) for t in ids.tolist()],
+                            max_new_tokens=min(sampling.max_new_tokens, self.max_total_tokens), eos_id=sampling.eos_id)
+            self.waiting.append(seq)
+            order.append(seq)
+        pending = None  # (batch, mode, ids on the host, copy-done event, new slots on the host)
+        while len(self.finished) < len(order) or pending is not None:
+            batch, mode = self._select_overlap(pending is not None)
+            if mode == "error" and pending is None:
+                raise RuntimeError("Insufficient memory to process any requests")
+            submitted = None
+            if batch:
+                self._next_staging()
+                if mode == "prefill":
+                    fb = self._prefill_batch(batch)
+                    n_new = [len(s.input_ids) - s.num_cached for s in batch]
+                    ends = self._h2d(torch.cumsum(torch.tensor(n_new), dim=0) - 1, torch.long)
+                    next_ids = torch.argmax(self._forward(mode, fb, ends), dim=-1)
+                    host_loc = None
+                    for s in batch:  # decodable from the next step on (scheduler.py:676-681)
+                        self.waiting.remove(s)
+                        self.decoding.append(s)
+                else:
+                    fb = self._decode_batch(batch, ids_on_device=True)
+                    next_ids = torch.argmax(self._forward(mode, fb), dim=-1)
+                    host_loc = [s.table[s.seq_len - 1] for s in batch]
+                self._last_ids[fb.req_pool_indices] = next_ids
+                for s in batch:
+                    s.in_flight += 1
+                if self.device.type == "cuda":
+                    if self._ids_host is None:
+                        self._ids_host = [torch.empty(self.max_requests, dtype=torch.long).pin_memory() for _ in range(3)]
+                    ids_host = self._ids_host[self._staging_turn][: len(batch)]
+                    ids_host.copy_(next_ids, non_blocking=True)
+                    done = torch.cuda.Event()
+                    done.record()
+                else:
+                    ids_host, done = next_ids.clone(), None
+                submitted = (batch, mode, ids_host, done, host_loc)
+            if pending is not None:
+                self._commit_overlap(*pending)
+            pending = submitted
+        return [s.output_ids for s in order]
+
+    def _select_overlap(self, step_in_flight: bool) -> Tuple[List[Sequence_], str]:
+        """``_select`` for a loop that has not seen the last step's ids yet: requests that have
+        stopped, or whose tokens in flight already fill their budget, are left out of decode
+        batches; a decode batch that could only be made by sending requests back to the queue is
+        put off ("wait") until the step in flight has been taken in."""
+        if self.waiting:
+            admitted = self._admit_prefill()
+            if admitted:
+                return admitted, "prefill"
+        live = [s for s in self.decoding if not s.finished and len(s.output_ids) + s.in_flight < s.max_new_tokens]
+        if not live:
+            return [], "error"
+        if step_in_flight and len(live) > self.token_to_kv_pool.available_size() + self.tree_cache.evictable_size():
+            return [], "wait"
+        held, self.decoding = self.decoding, live
+        try:
+            batch = self._select_decode()
+        finally:
+            kept = set(map(id, self.decoding))
+            live_ids = set(map(id, live))
+            self.decoding = [s for s in held if id(s) in kept or id(s) not in live_ids]
+        return (batch, "decode") if batch else ([], "error")
+
+    def _commit_overlap(self, batch, mode, ids_host, done, host_loc) -> None:
+        """Take in a finished step's ids (scheduler.py:700-761)."""
+        if done is not None:
+            done.synchronize()
+        for i, (s, tok) in enumerate(zip(batch, ids_host.tolist())):
+            s.in_flight -= 1
+            if s.finished:
+                # stopped on eos in the step before, found out too late: hand the extra slot back
+                s.table.pop()
+                s.seq_len -= 1
+                self.token_to_kv_pool.free(torch.tensor([host_loc[i]], dtype=torch.int32))
+                continue
+            s.output_ids.append(int(tok))
+            s.finished = len(s.output_ids) >= s.max_new_tokens or (s.eos_id != -1 and tok == s.eos_id)
+            if s.finished and s.in_flight == 0:
+                self._retire(s)
+            elif not s.finished and mode == "prefill":
+                self._cache_running(s)
+        for s in batch:
+            if s.finished and s.in_flight == 0 and s in self.decoding:
+                self._retire(s)
+
+    def _retire(self, s: Sequence_) -> None:
+        if s in self.decoding:
+            self.decoding.remove(s)
+        if s not in self.finished:
+            self._cache_finished(s)
+            self.finished.append(s)
+
+    def _forward(self, mode: str, fb: SimplifiedForwardBatch, rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Logits of the batch's tokens, or of token ``rows`` only (a model that takes
+        ``logits_rows`` then skips the vocabulary projection of every other token)."""
         if self.on_batch is not None:
             self.on_batch(mode, fb)
         with torch.no_grad():
-            return self.model(fb.input_ids, fb.positions, fb)
+            if rows is not None and getattr(self.model, "supports_logits_rows", False):
+                return self.model(fb.input_ids, fb.positions, fb, logits_rows=rows)
+            logits = self.model(fb.input_ids, fb.positions, fb)
+        return logits if rows is None else logits[rows]
 
     def _run_prefill(self, batch: List[Sequence_]) -> List[int]:
         """The admitted batch through the model, whole or in chunks; the token each
@@ -170,8 +332,8 @@ class ServingLoop:
         n_new = [len(s.input_ids) - s.num_cached for s in batch]
         limit = self.chunked_prefill_size
         if limit is None or sum(n_new) <= limit:
-            ends = torch.cumsum(torch.tensor(n_new), dim=0) - 1
-            return torch.argmax(self._forward("prefill", fb)[ends.to(self.device)], dim=-1).tolist()
+            ends = self._h2d(torch.cumsum(torch.tensor(n_new), dim=0) - 1, torch.long)
+            return torch.argmax(self._forward("prefill", fb, ends), dim=-1).tolist()
         next_ids: List[Optional[int]] = [None] * len(batch)
         first = [0]
         for n in n_new:
@@ -187,12 +349,16 @@ class ServingLoop:
                 out_cache_loc=fb.out_cache_loc[tok], req_to_token_pool=fb.req_to_token_pool,
                 token_to_kv_pool=fb.token_to_kv_pool, prefix_lens=prefix,
             )  # fmt: skip
-            logits = self._forward("prefill", chunk)
-            ends = (torch.cumsum(takes, dim=0) - 1).tolist()
+            ends, run = [], 0
+            for _, t in members:
+                run += t
+                ends.append(run - 1)
             finished = [(m, e) for (m, t), e in zip(members, ends) if done[m] + t == n_new[m]]
+            # (a call that completes no prompt still runs: it fills the cache for the next one)
+            rows = self._h2d([e for _, e in finished] or [0], torch.long)
+            logits = self._forward("prefill", chunk, rows)
             if finished:
-                rows = torch.tensor([e for _, e in finished], device=self.device)
-                for (m, _), tok_id in zip(finished, torch.argmax(logits[rows], dim=-1).tolist()):
+                for (m, _), tok_id in zip(finished, torch.argmax(logits, dim=-1).tolist()):
                     next_ids[m] = tok_id
             for m, t in members:
                 done[m] += t
@@ -266,12 +432,15 @@ class ServingLoop:
 
     # ---------------------------------------------------------------------------- batches
     def _alloc_slots(self, n: int) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
-        """(host copy, device tensor) of the next n free slots, or (None, None)."""
+        """(host copy, device tensor) of the next n free slots, or (None, None): the pool's
+        ``alloc`` (first n of the free list, memory_pool.py:68-74) with the copy to the device
+        made through pinned memory."""
         pool = self.token_to_kv_pool
         if n > pool.available_size():
             return None, None
         host = pool.free_slots[:n].clone()
-        return host, pool.alloc(n)
+        pool.free_slots = pool.free_slots[n:]
+        return host, self._h2d(host, torch.int32)
 
     def _prefill_batch(self, batch: List[Sequence_]) -> SimplifiedForwardBatch:
         r2t = self.req_to_token_pool
@@ -294,35 +463,39 @@ class ServingLoop:
             s.table = s.prefix_slots.tolist() + host_loc[used : used + n_new].tolist()
             mapping[i, : s.seq_len] = torch.tensor(s.table, dtype=torch.int32)
             used += n_new
-        dev = self.device
-        rows_t = torch.tensor(rows, dtype=torch.long, device=dev)
-        r2t.write(rows_t, mapping.to(dev))
+        rows_t = self._h2d(rows, torch.long)
+        r2t.write(rows_t, self._h2d(mapping, torch.int32))
         return SimplifiedForwardBatch.create_prefill_batch(
-            input_ids=torch.tensor(new_ids, dtype=torch.long, device=dev),
+            input_ids=self._h2d(new_ids, torch.long),
             req_pool_indices=rows_t,
-            seq_lens=torch.tensor([s.seq_len for s in batch], dtype=torch.long, device=dev),
+            seq_lens=self._h2d([s.seq_len for s in batch], torch.long),
             out_cache_loc=out_cache_loc,
             req_to_token_pool=r2t,
             token_to_kv_pool=self.token_to_kv_pool,
-            prefix_lens=torch.tensor([s.num_cached for s in batch], dtype=torch.long, device=dev),
+            prefix_lens=self._h2d([s.num_cached for s in batch], torch.long),
         )
 
-    def _decode_batch(self, batch: List[Sequence_]) -> SimplifiedForwardBatch:
+    def _decode_batch(self, batch: List[Sequence_], ids_on_device: bool = False) -> SimplifiedForwardBatch:
+        """One new token per request.  ``ids_on_device``: the tokens to feed are the ones the
+        requests' last steps left in the per-row id buffer (overlap mode), not ``output_ids[-1]``."""
         host_loc, new_slots = self._alloc_slots(len(batch))
         if host_loc is None:
             raise RuntimeError("Failed to allocate KV slots for decode")
         for s, slot in zip(batch, host_loc.tolist()):
-            if s.row is None or not s.output_ids:
+            if s.row is None or (not ids_on_device and not s.output_ids):
                 raise RuntimeError("request scheduled for decode without a page-table row or a token to feed")
             s.table.append(slot)  # position seq_len
             s.seq_len += 1
-        dev = self.device
-        rows_t = torch.tensor([s.row for s in batch], dtype=torch.long, device=dev)
-        seq_t = torch.tensor([s.seq_len for s in batch], dtype=torch.long, device=dev)
+        rows_t = self._h2d([s.row for s in batch], torch.long)
+        seq_t = self._h2d([s.seq_len for s in batch], torch.long)
         # one indexed write appends every request's new slot to its page-table row
         self.req_to_token_pool.req_to_token[rows_t, seq_t - 1] = new_slots
+        if ids_on_device:
+            input_ids = self._last_ids[rows_t]
+        else:
+            input_ids = self._h2d([s.output_ids[-1] for s in batch], torch.long)
         return SimplifiedForwardBatch.create_decode_batch(
-            input_ids=torch.tensor([s.output_ids[-1] for s in batch], dtype=torch.long, device=dev),
+            input_ids=input_ids,
             req_pool_indices=rows_t,
             seq_lens=seq_t,
             out_cache_loc=new_slots,
@@ -375,7 +548,7 @@ class ServingLoop:
         assert len(canon) == len(tokens)
         if len(canon) > n_old:
             s.table[n_old : len(canon)] = canon[n_old:].tolist()
-            self.req_to_token_pool.write((s.row, slice(n_old, len(canon))), canon[n_old:].to(self.device))
+            self.req_to_token_pool.write((s.row, slice(n_old, len(canon))), self._h2d(canon[n_old:], torch.int32))
         tree.dec_lock_ref(s.last_node)
         tree.inc_lock_ref(node)
         s.prefix_slots, s.last_node = canon, node

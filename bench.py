@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--layers", type=int, default=28)
     ap.add_argument("--max-context", type=int, default=4096)
-    ap.add_argument("--table", choices=["perm", "contig", "radix", "ragged"], default="perm")
+    ap.add_argument("--table", choices=["perm", "contig", "radix", "ragged", "pairs"], default="perm")
     ap.add_argument("--kv-layout", choices=["interleaved", "split"], default="interleaved")
     ap.add_argument("--variant", type=int, default=0, help="0 auto, 1 generic, 2 matrix-core decode kernel")
     ap.add_argument("--splits", type=int, default=0, help="sequence splits (0 = library heuristic)")
@@ -100,6 +100,10 @@ class Workload:
         for g0 in range(0, B, 8):
             t[g0 : g0 + 8, :half] = t[g0, :half]
         self.tables["radix"] = t
+        # requests 2i and 2i+1 name the same slots throughout: every KV byte is wanted twice, at the same time
+        t = self.tables["perm"].clone()
+        t[1::2] = t[0::2]
+        self.tables["pairs"] = t
         # ragged batch: lengths uniform in [S/2, 3S/2) with the same total work on average
         self.ragged_seq = torch.randint(max(1, S // 2), 3 * S // 2, (B,), generator=gen, device=dev, dtype=torch.int64)
         self.ragged_seq = layout.local_len(self.ragged_seq.clamp_max(args.max_context))

@@ -91,3 +91,27 @@ def test_chunked_prefill_gives_the_reference_ids(gpu, limit):
     outs = loop.run_batch(e2e["prompts"], SamplingParams(max_new_tokens=e2e["max_new_tokens"], eos_id=e2e["eos_id"]))
     assert [list(o) for o in outs] == [o.tolist() for o in e2e["output_ids"]]
     assert max(sizes) <= limit and len(sizes) > sum(1 for s in e2e["steps"] if s["mode"] == "prefill")
+
+
+def test_overlap_mode_on_the_gpu(gpu):
+    """Batches launched before the previous one's ids have been looked at (ids fed from the
+    device-side buffer, metadata through pinned staging): the reference's ids, also on a
+    second run that finds the prompts in the prefix tree, also with an eos that stops some
+    requests early (their extra step's slot is handed back)."""
+    from baby_sglang_amd.serving_loop import SamplingParams, ServingLoop
+
+    e2e = load_golden("driver_traces")["tiny_model_e2e"]
+    loop = ServingLoop(_tiny_model(gpu), max_total_tokens=e2e["max_total_tokens"], max_requests=e2e["max_requests"])
+    sp = SamplingParams(max_new_tokens=e2e["max_new_tokens"], eos_id=e2e["eos_id"])
+    want = [o.tolist() for o in e2e["output_ids"]]
+    assert [list(o) for o in loop.run_batch_overlap(e2e["prompts"], sp)] == want
+    assert [list(o) for o in loop.run_batch_overlap(e2e["prompts"], sp)] == want
+    # stop on the token that request 0 produces third
+    eos = want[0][2]
+    sp_eos = SamplingParams(max_new_tokens=e2e["max_new_tokens"], eos_id=eos)
+    plain = ServingLoop(_tiny_model(gpu), max_total_tokens=e2e["max_total_tokens"], max_requests=e2e["max_requests"])
+    a = plain.run_batch(e2e["prompts"], sp_eos)
+    b = loop.run_batch_overlap(e2e["prompts"], sp_eos)
+    assert a == b and len(a[0]) <= 3
+    assert loop.req_to_token_pool.available_size() == e2e["max_requests"]
+    assert loop.token_to_kv_pool.available_size() + loop.tree_cache.evictable_size() == e2e["max_total_tokens"]

@@ -151,3 +151,26 @@ def test_only_greedy_is_implemented():
     loop = ServingLoop(StandInModel(11), max_total_tokens=64, max_requests=2)
     with pytest.raises(NotImplementedError):
         loop.run_batch([torch.tensor([1, 2, 3])], SamplingParams(do_sample=True))
+
+
+@pytest.mark.parametrize("name", sorted(TRACES["scenarios"]))
+def test_overlap_mode_gives_the_same_ids(name):
+    """Ids looked at one step late (eos stops found out a step late, budget stops known ahead):
+    same outputs as the step-by-step loop, and everything handed back at the end."""
+    sc = TRACES["scenarios"][name]
+    loop = ServingLoop(StandInModel(TRACES["vocab"]), max_total_tokens=sc["max_total_tokens"], max_requests=sc["max_requests"])
+    modes = []
+    loop.on_batch = lambda mode, fb: modes.append((mode, len(fb.req_pool_indices)))
+    sp = SamplingParams(max_new_tokens=sc["max_new_tokens"], eos_id=sc["eos_id"])
+    outs = loop.run_batch_overlap(sc["prompts"], sp)
+    assert [list(o) for o in outs] == [o.tolist() for o in sc["output_ids"]]
+    assert loop.req_to_token_pool.available_size() == sc["max_requests"]
+    assert loop.token_to_kv_pool.available_size() + loop.tree_cache.evictable_size() == sc["max_total_tokens"]
+    assert all(s.in_flight == 0 for s in loop.finished)
+    # decode tokens run: one per produced token after the first, plus one extra step per eos stop
+    n_decode_tokens = sum(n for m, n in modes if m == "decode")
+    produced = sum(len(o) - 1 for o in outs)
+    assert produced <= n_decode_tokens <= produced + sum(1 for o in outs if sc["eos_id"] != -1 and o[-1] == sc["eos_id"])
+    # and again on the same loop, now with the prompts in the prefix tree
+    assert [list(o) for o in loop.run_batch_overlap(sc["prompts"], sp)] == [o.tolist() for o in sc["output_ids"]]
+    assert [list(o) for o in loop.run_batch(sc["prompts"], sp)] == [o.tolist() for o in sc["output_ids"]]
