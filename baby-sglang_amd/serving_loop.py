@@ -51,19 +51,7 @@ import torch
 from .forward_batch import SimplifiedForwardBatch
 from .memory_pool import MHATokenToKVPool, ReqToTokenPool
 from .prefix_cache import PrefixCache, PrefixNode
-
-
-@dataclass
-class SamplingParams:
-    """Fields of the reference's ``SamplingParams`` (sample.py:8-17)."""
-
-    max_new_tokens: int = 64
-    temperature: float = 1.0
-    top_k: int = 0
-    top_p: float = 1.0
-    eos_id: int = -1
-    do_sample: bool = False
-    repetition_penalty: float = 1.0
+from .sampling import SamplingParams, sample_next_ids
 
 
 @dataclass(eq=False)
@@ -144,6 +132,8 @@ class ServingLoop:
         self._staging_turn = 0
         self._staging_used = 0
         self._last_ids = None  # device: the id each page-table row's request produced last
+        self._sampling = SamplingParams()
+        self.generator: Optional[torch.Generator] = None  # for do_sample; None = the device's default generator
         self._ids_host = None  # pinned landing buffers of the per-step id copies, in the same rotation
 
     def reset(self) -> None:
@@ -182,8 +172,7 @@ class ServingLoop:
     # ---------------------------------------------------------------------------- the loop
     def run_batch(self, requests: Sequence[torch.Tensor], sampling: Optional[SamplingParams] = None) -> List[List[int]]:
         sampling = sampling or SamplingParams()
-        if sampling.do_sample or sampling.repetition_penalty > 1.0:
-            raise NotImplementedError("only greedy decoding is implemented in this driver")
+        self._sampling = sampling
         self.waiting, self.decoding, self.finished = [], [], []
         self.est_new_token_ratio = self.r_init
         order = []
@@ -200,7 +189,7 @@ class ServingLoop:
                 next_ids = self._run_prefill(batch)
             else:
                 fb = self._decode_batch(batch)
-                next_ids = torch.argmax(self._forward(mode, fb), dim=-1).tolist()
+                next_ids = self._pick(self._forward(mode, fb), batch).tolist()
             self._finish_step(next_ids, batch, mode)
         return [s.output_ids for s in order]
 
@@ -209,8 +198,9 @@ class ServingLoop:
         building and launching the next batch overlaps the current one on the GPU.  Same
         output ids as ``run_batch``."""
         sampling = sampling or SamplingParams()
-        if sampling.do_sample or sampling.repetition_penalty > 1.0:
-            raise NotImplementedError("only greedy decoding is implemented in this driver")
+        # (the repetition penalty is left out in this mode, as in the reference, scheduler.py:632:
+        # it needs the ids of the step in flight)
+        self._sampling = SamplingParams(**{**sampling.__dict__, "repetition_penalty": 1.0})
         if self.chunked_prefill_size is not None:
             raise NotImplementedError("overlap mode runs whole-prompt prefill batches")
         self.waiting, self.decoding, self.finished = [], [], []
@@ -235,14 +225,14 @@ class ServingLoop:
                     fb = self._prefill_batch(batch)
                     n_new = [len(s.input_ids) - s.num_cached for s in batch]
                     ends = self._h2d(torch.cumsum(torch.tensor(n_new), dim=0) - 1, torch.long)
-                    next_ids = torch.argmax(self._forward(mode, fb, ends), dim=-1)
+                    next_ids = self._pick(self._forward(mode, fb, ends), batch)
                     host_loc = None
                     for s in batch:  # decodable from the next step on (scheduler.py:676-681)
                         self.waiting.remove(s)
                         self.decoding.append(s)
                 else:
                     fb = self._decode_batch(batch, ids_on_device=True)
-                    next_ids = torch.argmax(self._forward(mode, fb), dim=-1)
+                    next_ids = self._pick(self._forward(mode, fb), batch)
                     host_loc = [s.table[s.seq_len - 1] for s in batch]
                 self._last_ids[fb.req_pool_indices] = next_ids
                 for s in batch:
@@ -314,6 +304,14 @@ class ServingLoop:
             self._cache_finished(s)
             self.finished.append(s)
 
+    def _pick(self, logits: torch.Tensor, batch: List[Sequence_]) -> torch.Tensor:
+        """One id per request from its row of ``logits``: the whole batch at once, on the device
+        (scheduler.py:523-546 does it request by request)."""
+        sp = self._sampling
+        prev = [s.output_ids for s in batch] if sp.repetition_penalty > 1.0 else None
+        return sample_next_ids(logits, sp.do_sample, sp.temperature, sp.top_k, sp.top_p, prev, sp.repetition_penalty,
+                               generator=self.generator)
+
     def _forward(self, mode: str, fb: SimplifiedForwardBatch, rows: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Logits of the batch's tokens, or of token ``rows`` only (a model that takes
         ``logits_rows`` then skips the vocabulary projection of every other token)."""
@@ -333,7 +331,7 @@ class ServingLoop:
         limit = self.chunked_prefill_size
         if limit is None or sum(n_new) <= limit:
             ends = self._h2d(torch.cumsum(torch.tensor(n_new), dim=0) - 1, torch.long)
-            return torch.argmax(self._forward("prefill", fb, ends), dim=-1).tolist()
+            return self._pick(self._forward("prefill", fb, ends), batch).tolist()
         next_ids: List[Optional[int]] = [None] * len(batch)
         first = [0]
         for n in n_new:
@@ -358,7 +356,7 @@ class ServingLoop:
             rows = self._h2d([e for _, e in finished] or [0], torch.long)
             logits = self._forward("prefill", chunk, rows)
             if finished:
-                for (m, _), tok_id in zip(finished, torch.argmax(logits, dim=-1).tolist()):
+                for (m, _), tok_id in zip(finished, self._pick(logits, [batch[m] for m, _ in finished]).tolist()):
                     next_ids[m] = tok_id
             for m, t in members:
                 done[m] += t

@@ -147,10 +147,27 @@ def test_least_recently_used_leaf_goes_first():
     assert freed == [3, 4]
 
 
-def test_only_greedy_is_implemented():
-    loop = ServingLoop(StandInModel(11), max_total_tokens=64, max_requests=2)
-    with pytest.raises(NotImplementedError):
-        loop.run_batch([torch.tensor([1, 2, 3])], SamplingParams(do_sample=True))
+def test_sampled_decoding_is_reproducible_and_differs_from_greedy():
+    class Spread(StandInModel):
+        def forward(self, input_ids, positions, forward_batch, input_embeds=None):
+            v = self.config.vocab_size
+            base = torch.arange(v, dtype=torch.float32)
+            return torch.cos(base[None, :] * (1 + input_ids[:, None] % 7) + positions[:, None].float())
+
+    prompts = [torch.tensor([1, 2, 3, 4]), torch.tensor([9, 8, 7])]
+    sp = SamplingParams(max_new_tokens=12, do_sample=True, temperature=0.9, top_k=5, top_p=0.95, repetition_penalty=1.2)
+    outs = []
+    for _ in range(2):
+        loop = ServingLoop(Spread(23), max_total_tokens=128, max_requests=2)
+        loop.generator = torch.Generator().manual_seed(4)
+        outs.append(loop.run_batch(prompts, sp))
+    assert outs[0] == outs[1]
+    greedy = ServingLoop(Spread(23), max_total_tokens=128, max_requests=2).run_batch(prompts, SamplingParams(max_new_tokens=12))
+    assert greedy != outs[0]
+    loop = ServingLoop(Spread(23), max_total_tokens=128, max_requests=2)
+    loop.generator = torch.Generator().manual_seed(4)
+    over = loop.run_batch_overlap(prompts, SamplingParams(max_new_tokens=12, do_sample=True, temperature=0.9, top_k=5))
+    assert all(len(o) == 12 for o in over)
 
 
 @pytest.mark.parametrize("name", sorted(TRACES["scenarios"]))
