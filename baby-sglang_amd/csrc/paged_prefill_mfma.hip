@@ -19,7 +19,14 @@
 // position and 4 + 4 tokens, which is exactly the 8 k-values per lane of a 16x16x32
 // product -- the summation order over tokens is free as long as P and V^T agree on
 // it, so the two tiles' probability fragments and transposed V fragments are simply
-// concatenated and PV runs at the full-rate 16x16x32 shape.  The waves of a
+// concatenated and PV runs at the full-rate 16x16x32 shape.  Probabilities enter the PV
+// product once, rounded to the dtype (the decode kernel's two-operand split of bf16
+// probabilities would be a third of this kernel's matrix work), and the softmax
+// denominator comes out of the matrix cores as well: one more 16x16x32 product of the same
+// probability fragment with a fragment of ones accumulates, in the rows' own layout, the
+// sum of the ROUNDED probabilities -- so numerator and denominator carry the same rounding
+// and the output is an exact convex combination of V rows -- and replaces eight vector adds
+// per head and step.  The waves of a
 // workgroup share every K/V step: each issues a quarter of its DMA, waits for its
 // own share, and one barrier per step both publishes it and retires the stage that
 // the step after next will overwrite (3-stage ring).
@@ -158,12 +165,15 @@ void prefill_mfma_kernel(PrefillArgs a) {
   // the score / softmax half and in the PV half of its steps, and the step count
   const bool PROF = a.prof != nullptr;
   uint64_t prof[6] = {0, 0, 0, 0, 0, 0};
-  float m_run[RT], l_run[RT];
+  float m_run[RT];
   f32x4 o_acc[RT][8];
+  f32x4 l_acc[RT];  // row sums of the probabilities, rows as in o_acc (the same value in every column)
+  const uint32_t one2 = E::pack2(1.f, 1.f);
+  const uint4 ones = make_uint4(one2, one2, one2, one2);
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     m_run[rt] = kNegInf;
-    l_run[rt] = 0.f;
+    l_acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int n = 0; n < 8; ++n) o_acc[rt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -226,7 +236,7 @@ void prefill_mfma_kernel(PrefillArgs a) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) kf[u][s] = *(const uint4*)(st + u * TILE_BYTES + k_off[s]);
 
-      uint4 pf[RT][PFrag<Tag>::N];
+      uint4 pf[RT];
       const uint64_t t4 = PROF ? __builtin_readcyclecounter() : 0;
       // scores, running max and probabilities of each q head for this step.  The running max
       // is kept in raw score units and the scale enters once, inside the exponent:
@@ -261,10 +271,11 @@ void prefill_mfma_kernel(PrefillArgs a) {
           // a column with nothing visible yet keeps m = -inf: its factor is 1, not exp2(nan)
           const float alpha = m_new == kNegInf ? 1.f : fast_exp2((m_run[rt] - m_new) * scale_log2e);
           m_run[rt] = m_new;
-          l_run[rt] *= alpha;
           float ar[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * lg + r);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) l_acc[rt][r] *= ar[r];
 #pragma unroll
           for (int n = 0; n < 8; ++n)
 #pragma unroll
@@ -276,12 +287,10 @@ void prefill_mfma_kernel(PrefillArgs a) {
         for (int r = 0; r < 4; ++r) {
           pa[r] = fast_exp2(fmaf(raw[r], scale_log2e, neg_mc));
           pb[r] = fast_exp2(fmaf(raw[4 + r], scale_log2e, neg_mc));
-          l_run[rt] += pa[r] + pb[r];
         }
         // k-values 0-3 of the lane: its tokens of tile 0, k-values 4-7: those of tile 1
-        const PFrag<Tag> fa(pa), fb(pb);
-#pragma unroll
-        for (int k = 0; k < PFrag<Tag>::N; ++k) pf[rt][k] = make_uint4(fa.f[k].x, fa.f[k].y, fb.f[k].x, fb.f[k].y);
+        pf[rt] = make_uint4(E::pack2(pa[0], pa[1]), E::pack2(pa[2], pa[3]), E::pack2(pb[0], pb[1]), E::pack2(pb[2], pb[3]));
+        l_acc[rt] = Mma<Tag>::pv32(pf[rt], ones, l_acc[rt]);
       }
       const uint64_t t5 = PROF ? __builtin_readcyclecounter() : 0;
 #pragma unroll
@@ -293,9 +302,7 @@ void prefill_mfma_kernel(PrefillArgs a) {
         const uint2 va2 = __builtin_bit_cast(uint2, va), vb2 = __builtin_bit_cast(uint2, vb);
         const uint4 vf = make_uint4(va2.x, va2.y, vb2.x, vb2.y);
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-          for (int k = 0; k < PFrag<Tag>::N; ++k) o_acc[rt][n] = Mma<Tag>::pv32(pf[rt][k], vf, o_acc[rt][n]);
+        for (int rt = 0; rt < RT; ++rt) o_acc[rt][n] = Mma<Tag>::pv32(pf[rt], vf, o_acc[rt][n]);
       }
       if (PROF) {
         const uint64_t t6 = __builtin_readcyclecounter();
@@ -315,11 +322,9 @@ void prefill_mfma_kernel(PrefillArgs a) {
   float* o_lds = (float*)(smem + wave * STAGE_OUT);
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
-    const float l = quad_group_sum(l_run[rt]);
-    const float inv = l > 0.f ? 1.f / l : 0.f;
     float ir[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) ir[r] = __shfl(inv, 4 * lg + r);
+    for (int r = 0; r < 4; ++r) ir[r] = l_acc[rt][r] > 0.f ? 1.f / l_acc[rt][r] : 0.f;
 #pragma unroll
     for (int n = 0; n < 8; ++n)
 #pragma unroll

@@ -449,8 +449,21 @@ def test_prefill_kernels_agree(gpu, dtype, hq, hkv):
             cpu["seq_lens"].to(gpu), pl.to(gpu), el.to(gpu))
     got_mfma = _hip.paged_prefill(*args, variant=2)
     got_valu = _hip.paged_prefill(*args, variant=1)
-    assert_close(got_mfma, want, dtype, "matrix-core extend")
     assert_close(got_valu, want, dtype, "generic extend")
+    if dtype == torch.bfloat16:
+        # The matrix-core kernel rounds each probability to bf16 once before P V (as torch's
+        # SDPA, i.e. the reference, does; its own distance to the float64 definition on the golden
+        # cases is up to 1.2e-2).  That is a relative error of at most 2^-8 per term of
+        # sum_t p_t v_t, so the output may move by 2^-8 * sum_t p_t |v_t| -- the same attention
+        # over |V| -- on top of the rounding of the result itself.
+        spread = orc.prefill_exact(q, cpu["k_slab"], cpu["v_slab"].abs(), cpu["req_to_token"],
+                                   cpu["req_pool_indices"], cpu["seq_lens"], pl, el)
+        err = (got_mfma.double().cpu() - want).abs()
+        bound = 2.0**-8 * want.abs() + 2.0**-8 * spread + 1e-4
+        assert bool((err <= bound).all()), f"matrix-core extend: worst excess {(err - bound).max().item():.3e}"
+        assert err.mean().item() < 1.5e-3
+    else:
+        assert_close(got_mfma, want, dtype, "matrix-core extend")
 
 
 def test_side_stream_and_thread(gpu):
