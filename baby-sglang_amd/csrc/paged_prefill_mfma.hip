@@ -215,7 +215,11 @@ void prefill_mfma_kernel(PrefillArgs a) {
     issue_step(0);
     if (n_steps > 1) issue_step(1);
 
-    for (int step = 0; step < n_steps; ++step) {
+    // one step; STAGE = step % NSTAGE as a compile-time value, so that every LDS read of the
+    // step addresses its ring stage through the instruction's immediate offset instead of a
+    // vector add per read
+    auto do_step = [&](int step, auto stage_c) {
+      constexpr int STAGE = decltype(stage_c)::value;
       const uint64_t t0 = PROF ? __builtin_readcyclecounter() : 0;
       // this wave's share of the step has landed (one younger step may stay in flight) ...
       if (step + 1 < n_steps) dma_wait<DPW>(); else dma_wait<0>();
@@ -226,9 +230,9 @@ void prefill_mfma_kernel(PrefillArgs a) {
       if (step + 2 < n_steps) issue_step(step + 2);  // into the stage step - 1 used
       const uint64_t t3 = PROF ? __builtin_readcyclecounter() : 0;
       if (PROF) { prof[0] += t1 - t0; prof[1] += t2 - t1; prof[2] += t3 - t2; prof[5] += 1; }
-      const char* st = smem + (step % NSTAGE) * STEP_BYTES;
+      const char* st = smem + STAGE * STEP_BYTES;
       const int tok0 = blk + step * STEP + 4 * lg;  // first of this lane's tokens in tile 0; tile 1: + 16
-      if (blk + step * STEP >= wave_len) continue;  // nothing this wave's rows may see (wave-uniform)
+      if (blk + step * STEP >= wave_len) return;  // nothing this wave's rows may see (wave-uniform)
 
       uint4 kf[2][4];
 #pragma unroll
@@ -309,6 +313,12 @@ void prefill_mfma_kernel(PrefillArgs a) {
         prof[3] += t5 - t4;
         prof[4] += t6 - t5;
       }
+    };
+    static_assert(NSTAGE == 3, "the step loop below is unrolled over the ring");
+    for (int step = 0; step < n_steps; step += 3) {
+      do_step(step, std::integral_constant<int, 0>{});
+      if (step + 1 < n_steps) do_step(step + 1, std::integral_constant<int, 1>{});
+      if (step + 2 < n_steps) do_step(step + 2, std::integral_constant<int, 2>{});
     }
   }
 
