@@ -103,7 +103,13 @@ void decode_mfma_kernel(DecodeArgs a) {
     // (head group fastest: the workgroups of a piece's kv heads run side by side and read the
     // same DRAM pages together; measured 1 % faster than all pieces of a head group first, and
     // equal to putting the two in one two-wave workgroup)
-    hg = (int)(blockIdx.x % (unsigned)n_hg);
+    // The head groups take the launch indices in DESCENDING order (group n_hg - 1 first).  Two
+    // things were measured on every launch of the headline batch, each worth about 1.2 us of
+    // streaming time: workgroups on odd launch indices (dealt to the odd XCDs) stream slower
+    // than those on even ones, and so do the workgroups of head group 1 compared with head
+    // group 0, whichever index they have.  In ascending order the two fall on the same
+    // workgroups; in descending order they cancel (1.2 % of the step).  Placement only.
+    hg = n_hg - 1 - (int)(blockIdx.x % (unsigned)n_hg);
     const int piece = (int)(blockIdx.x / (unsigned)n_hg);
     // per-lane request data, 64 rows at a time; the first block is loaded once for both passes
     auto len_of = [&](int i) {
