@@ -262,10 +262,14 @@ void prefill_mfma_kernel(PrefillArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) raw[4 * u + r] = sc[u][r];
         if (step_masked) {
+          // (the comparisons hang on a value the compiler cannot see through, or it makes all
+          // eight of them in every step, masked or not)
+          int t0m = tok0;
+          asm volatile("" : "+v"(t0m));
 #pragma unroll
           for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) raw[4 * u + r] = (tok0 + 16 * u + r <= my_last) ? raw[4 * u + r] : kNegInf;
+            for (int r = 0; r < 4; ++r) raw[4 * u + r] = (t0m + 16 * u + r <= my_last) ? raw[4 * u + r] : kNegInf;
         }
         float tmax = fmaxf(fmaxf(fmaxf(raw[0], raw[1]), fmaxf(raw[2], raw[3])),
                            fmaxf(fmaxf(raw[4], raw[5]), fmaxf(raw[6], raw[7])));
