@@ -165,7 +165,9 @@ void prefill_mfma_kernel(PrefillArgs a) {
   // the score / softmax half and in the PV half of its steps, and the step count
   const bool PROF = a.prof != nullptr;
   uint64_t prof[6] = {0, 0, 0, 0, 0, 0};
-  float m_run[RT];
+  float m_run[RT], neg_mc[RT];  // reference score of the lane's row, and -(that) * scale * log2(e)
+  constexpr float kSlack = 6.f;
+  const float slack_raw = kSlack / scale_log2e;
   f32x4 o_acc[RT][8];
   f32x4 l_acc[RT];  // row sums of the probabilities, rows as in o_acc (the same value in every column)
   const uint32_t one2 = E::pack2(1.f, 1.f);
@@ -173,6 +175,7 @@ void prefill_mfma_kernel(PrefillArgs a) {
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     m_run[rt] = kNegInf;
+    neg_mc[rt] = 0.f;
     l_acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int n = 0; n < 8; ++n) o_acc[rt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -271,14 +274,21 @@ void prefill_mfma_kernel(PrefillArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) raw[4 * u + r] = (t0m + 16 * u + r <= my_last) ? raw[4 * u + r] : kNegInf;
         }
-        float tmax = fmaxf(fmaxf(fmaxf(raw[0], raw[1]), fmaxf(raw[2], raw[3])),
-                           fmaxf(fmaxf(raw[4], raw[5]), fmaxf(raw[6], raw[7])));
-        tmax = quad_group_max(tmax);
-        if (__any(tmax > m_run[rt])) {
+        // Lazy running maximum.  Softmax needs ONE reference value per row that all four lane
+        // groups agree on, not the exact maximum: p = exp2((s - m) c) stays correct under any m as
+        // long as it cannot overflow, because the row sums carry the same factor.  So the exact
+        // maximum (two cross-lane exchanges) and the rescale are only done when some lane sees a
+        // score more than kSlack (in exponent units) above the row's reference; until then
+        // probabilities may reach 2^kSlack, which f32 sums and bf16 / f16 operands hold easily.
+        const float lmax = fmaxf(fmaxf(fmaxf(raw[0], raw[1]), fmaxf(raw[2], raw[3])),
+                                 fmaxf(fmaxf(raw[4], raw[5]), fmaxf(raw[6], raw[7])));
+        if (__any(lmax > m_run[rt] + slack_raw)) {
+          const float tmax = quad_group_max(lmax);
           const float m_new = fmaxf(m_run[rt], tmax);
           // a column with nothing visible yet keeps m = -inf: its factor is 1, not exp2(nan)
           const float alpha = m_new == kNegInf ? 1.f : fast_exp2((m_run[rt] - m_new) * scale_log2e);
           m_run[rt] = m_new;
+          neg_mc[rt] = -(m_new == kNegInf ? 0.f : m_new) * scale_log2e;  // masked scores: exp2(-inf) = 0
           float ar[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) ar[r] = __shfl(alpha, 4 * lg + r);
@@ -289,12 +299,11 @@ void prefill_mfma_kernel(PrefillArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) o_acc[rt][n][r] *= ar[r];
         }
-        const float neg_mc = -(m_run[rt] == kNegInf ? 0.f : m_run[rt]) * scale_log2e;  // masked scores: exp2(-inf) = 0
         float pa[4], pb[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          pa[r] = fast_exp2(fmaf(raw[r], scale_log2e, neg_mc));
-          pb[r] = fast_exp2(fmaf(raw[4 + r], scale_log2e, neg_mc));
+          pa[r] = fast_exp2(fmaf(raw[r], scale_log2e, neg_mc[rt]));
+          pb[r] = fast_exp2(fmaf(raw[4 + r], scale_log2e, neg_mc[rt]));
         }
         // k-values 0-3 of the lane: its tokens of tile 0, k-values 4-7: those of tile 1
         pf[rt] = make_uint4(E::pack2(pa[0], pa[1]), E::pack2(pa[2], pa[3]), E::pack2(pb[0], pb[1]), E::pack2(pb[2], pb[3]));

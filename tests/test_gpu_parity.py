@@ -466,6 +466,38 @@ def test_prefill_kernels_agree(gpu, dtype, hq, hkv):
         assert_close(got_mfma, want, dtype, "matrix-core extend")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("slope", [0.02, 0.4])
+def test_extend_scores_rising_along_the_sequence(gpu, dtype, slope):
+    """Scores that keep growing with the token position: the extend kernel's running reference
+    value (renewed only when a score exceeds it by a margin) must be renewed again and again --
+    slowly (several steps per renewal) and fast (every step) -- and late tokens dominate."""
+    from baby_sglang_amd import _hip
+
+    hq, hkv, dim = 4, 2, 128
+    seq_lens, prefix_lens = [900, 330, 64], [512, 0, 63]
+    cpu, r2t, kv = random_decode_problem(gpu, dtype, hq, hkv, dim, seq_lens, seed=5)
+    for i, n in enumerate(seq_lens):
+        slots = cpu["req_to_token"][i, :n].long()
+        cpu["k_slab"][slots, :, 0] = (slope * torch.arange(n, dtype=torch.float32))[:, None].to(dtype)
+    kv.k_buffer[0].copy_(cpu["k_slab"])
+    ext = [s - p for s, p in zip(seq_lens, prefix_lens)]
+    gen = torch.Generator().manual_seed(3)
+    q = torch.randn((sum(ext), hq, dim), generator=gen)
+    q[:, :, 0] = 8.0
+    q = q.to(dtype)
+    pl, el = torch.tensor(prefix_lens), torch.tensor(ext)
+    want = orc.prefill_exact(q, cpu["k_slab"], cpu["v_slab"], cpu["req_to_token"], cpu["req_pool_indices"], cpu["seq_lens"], pl, el)
+    spread = orc.prefill_exact(q, cpu["k_slab"], cpu["v_slab"].abs(), cpu["req_to_token"], cpu["req_pool_indices"], cpu["seq_lens"], pl, el)
+    k_slab, v_slab = kv.get_kv_buffer(0)
+    got = _hip.paged_prefill(q.to(gpu), k_slab, v_slab, r2t.req_to_token, cpu["req_pool_indices"].to(gpu),
+                             cpu["seq_lens"].to(gpu), pl.to(gpu), el.to(gpu), variant=2)
+    ulp = 2.0**-8 if dtype == torch.bfloat16 else 2.0**-11
+    err = (got.double().cpu() - want).abs()
+    bound = ulp * want.abs() + ulp * spread + 2e-4
+    assert bool(torch.isfinite(got).all()) and bool((err <= bound).all()), f"worst excess {(err - bound).max().item():.3e}"
+
+
 def test_side_stream_and_thread(gpu):
     """The reference calls its backend from a worker thread inside a side stream
     (overlap_worker.py:104-127); results must not depend on either."""
