@@ -15,9 +15,10 @@ their q-head groups, its own KV slabs and nothing to merge).  When the world is
 larger than the number of kv heads (Qwen2.5-1.5B has 2), the ranks of a kv head
 additionally split every request's tokens round-robin by position, each rank
 holding its tokens in its own pool under a local page table; partial results
-``(o, lse)`` are exchanged with ONE all-gather per layer and merged by
-``bsgl_merge_attn_states``.  Messages are ~100-200 KiB, i.e. latency-bound on
-xGMI, so there is exactly one collective per layer and no ring of small steps.
+``(o, lse)`` are traded inside the kv head's group of ranks (one all-to-all: each rank
+merges a share of the rows with ``bsgl_merge_attn_states``) and the merged rows are
+all-gathered.  Messages are 0.1 - 1.5 MB, latency-bound on xGMI, so there are at most two
+collectives per layer and no ring of small steps.
 """
 
 from __future__ import annotations
@@ -168,6 +169,37 @@ class TPLayout:
         return kv[:, lo:hi]
 
 
+_SEQ_GROUPS = {}
+
+
+def seq_slice_group(layout: TPLayout, tp_group):
+    """The process group of the ranks that hold the same kv heads as this rank (its
+    sequence-slice peers).  Created once per (world, tp_seq) -- by every rank, for every kv
+    shard, in the same order, as ``new_group`` demands."""
+    if layout.tp_seq == 1 or not dist.is_initialized():
+        return None
+    if layout.tp_kv == 1:
+        return tp_group
+    key = (layout.world, layout.tp_seq)
+    if key not in _SEQ_GROUPS:
+        groups = [dist.new_group(list(range(k * layout.tp_seq, (k + 1) * layout.tp_seq))) for k in range(layout.tp_kv)]
+        _SEQ_GROUPS[key] = groups
+    return _SEQ_GROUPS[key][layout.kv_rank]
+
+
+def tp_all_to_all(x: torch.Tensor, group) -> torch.Tensor:
+    """``out[j] = (rank j's x)[this rank's index]`` over dim 0 (one equal piece per rank)."""
+    out = torch.empty_like(x)
+    if x.is_cuda and dist.get_backend(group) == "gloo":
+        # (gloo has no device all-to-all: host staging, rehearsals only)
+        host = torch.empty(x.shape, dtype=x.dtype)
+        dist.all_to_all_single(host, x.contiguous().cpu(), group=group)
+        out.copy_(host)
+        return out
+    dist.all_to_all_single(out, x.contiguous(), group=group)
+    return out
+
+
 def tp_attention_exchange(
     layout: TPLayout,
     local_out: torch.Tensor,
@@ -180,9 +212,16 @@ def tp_attention_exchange(
 
     ``local_out`` is this rank's ``[rows, local_q_heads * head_dim]`` result: in
     ``out_dtype`` when tokens are not split (tp_seq == 1), fp32 with
-    ``local_lse`` ``[rows, local_q_heads]`` otherwise.  One all-gather either way.
-    ``merge_fn(parts_o [P,R,H,D], parts_lse [P,R,H], dtype) -> [R, H*D]``
-    defaults to the HIP merge kernel.
+    ``local_lse`` ``[rows, local_q_heads]`` otherwise.
+
+    tp_seq == 1: one all-gather of the rows.  tp_seq > 1: the ranks that share kv heads
+    first trade their partial states so that each merges ``rows / tp_seq`` of the rows (one
+    all-to-all inside that group: every rank sends ``(tp_seq - 1) / tp_seq`` of its fp32
+    state and nothing is sent twice), then the merged rows -- now in ``out_dtype``, a sixth of
+    the state's bytes per row -- go round the whole group in one all-gather.  Against
+    gathering every rank's whole fp32 state everywhere this moves 4.5 x fewer bytes at 8 ranks.
+    ``merge_fn(parts_o [P,R,H,D], parts_lse [P,R,H], dtype) -> [R, H*D]`` defaults to the HIP
+    merge kernel.
     """
     rows = local_out.shape[0]
     hq_l = layout.local_q_heads
@@ -196,11 +235,16 @@ def tp_attention_exchange(
         from . import _hip
 
         merge_fn = _hip.merge_attn_states
-    state = torch.cat(
-        (local_out.view(rows, hq_l, dim).float(), local_lse.view(rows, hq_l, 1).float()), dim=-1
-    )
-    gathered = tp_all_gather(state.unsqueeze(0), tp_group)  # [world, rows, hq_l, D+1]
-    gathered = gathered.view(layout.tp_kv, layout.tp_seq, rows, hq_l, dim + 1)
-    parts = gathered.permute(1, 0, 2, 3, 4).reshape(layout.tp_seq, layout.tp_kv * rows, hq_l, dim + 1)
-    merged = merge_fn(parts[..., :dim].contiguous(), parts[..., dim].contiguous(), out_dtype)
-    return merged.view(layout.tp_kv, rows, hq_l * dim).permute(1, 0, 2).reshape(rows, layout.n_q_heads * dim)
+    n_seq = layout.tp_seq
+    chunk = (rows + n_seq - 1) // n_seq  # rows each peer merges (the last chunk may be padded)
+    state = torch.empty((n_seq * chunk, hq_l, dim + 1), dtype=torch.float32, device=local_out.device)
+    state[:rows, :, :dim] = local_out.view(rows, hq_l, dim)
+    state[:rows, :, dim] = local_lse.view(rows, hq_l)
+    if n_seq * chunk > rows:
+        state[rows:, :, :dim] = 0
+        state[rows:, :, dim] = float("-inf")  # weight 0 everywhere: the merge gives zeros
+    parts = tp_all_to_all(state.view(n_seq, chunk, hq_l, dim + 1), seq_slice_group(layout, tp_group))
+    merged = merge_fn(parts[..., :dim].contiguous(), parts[..., dim].contiguous(), out_dtype)  # [chunk, hq_l*D]
+    gathered = tp_all_gather(merged.view(1, chunk, hq_l * dim), tp_group)  # [world, chunk, hq_l*D]
+    full = gathered.view(layout.tp_kv, n_seq, chunk, hq_l * dim).permute(1, 2, 0, 3)
+    return full.reshape(n_seq * chunk, layout.n_q_heads * dim)[:rows]

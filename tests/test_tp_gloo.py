@@ -40,9 +40,9 @@ def _worker(rank, world, port, n_kv_heads):
 
     # --- the four wrappers
     x = torch.full((3,), float(rank + 1))
-    assert tp.tp_all_reduce_sum(x, group) is x and x.tolist() == [3.0] * 3
+    assert tp.tp_all_reduce_sum(x, group) is x and x.tolist() == [world * (world + 1) / 2] * 3
     g = tp.tp_all_gather(torch.full((2, 2), float(rank)), group)
-    assert tuple(g.shape) == (4, 2) and g[:2].eq(0).all() and g[2:].eq(1).all()
+    assert tuple(g.shape) == (2 * world, 2) and all(bool(g[2 * r : 2 * r + 2].eq(r).all()) for r in range(world))
     b = torch.tensor([7.0 if rank == 1 else 0.0])
     assert tp.tp_broadcast(b, 1, group) is b and b.item() == 7.0
 
@@ -50,12 +50,12 @@ def _worker(rank, world, port, n_kv_heads):
     hq, dim = 4 * n_kv_heads, 64
     layout = tp.TPLayout(rank, world, hq, n_kv_heads)
     gen = torch.Generator().manual_seed(0)  # same data on both ranks
-    seq_lens = [5, 12, 1, 9]
+    seq_lens = [5, 12, 1, 9, 30] if world > 2 else [5, 12, 1, 9]  # (5 rows over 2 slices: a padded share)
     n_slots = sum(seq_lens) + 1
     k_slab = torch.randn((n_slots, n_kv_heads, dim), generator=gen)
     v_slab = torch.randn((n_slots, n_kv_heads, dim), generator=gen)
     q = torch.randn((len(seq_lens), hq, dim), generator=gen)
-    table = torch.zeros((len(seq_lens), 16), dtype=torch.int32)
+    table = torch.zeros((len(seq_lens), 32), dtype=torch.int32)
     perm = torch.randperm(n_slots - 1, generator=gen) + 1
     used = 0
     for i, n in enumerate(seq_lens):
@@ -89,6 +89,12 @@ def _worker(rank, world, port, n_kv_heads):
 @pytest.mark.parametrize("n_kv_heads", [2, 1])
 def test_two_ranks(n_kv_heads):
     mp.spawn(_worker, args=(2, _free_port(), n_kv_heads), nprocs=2, join=True)
+
+
+def test_four_ranks_two_kv_shards_of_two_sequence_slices():
+    """world 4 over 2 kv heads: the partial states are traded inside each kv head's pair of
+    ranks (a sub-group), the merged rows gathered over all four."""
+    mp.spawn(_worker, args=(4, _free_port(), 2), nprocs=4, join=True)
 
 
 def test_layouts():
