@@ -132,25 +132,33 @@ void decode_mfma_kernel(DecodeArgs a) {
     const int want = a.rows * a.balance_target;
     int piece_len = max((tot + want - 1) / want, (longest + a.n_splits - 1) / a.n_splits);
     piece_len = max(kTile, (piece_len + kTile - 1) / kTile * kTile);
-    int base = 0;
-    row = -1;
-    for (int r0 = 0; r0 < a.rows; r0 += 64) {
-      const int s = r0 == 0 ? len0 : len_of(r0 + lane);
-      const int parts = r0 + lane < a.rows ? min(a.n_splits, max(1, (s + piece_len - 1) / piece_len)) : 0;
-      const int incl = wave_inclusive_scan<ScanAdd>(parts);
-      const int blk_total = __builtin_amdgcn_readlane(incl, 63);
-      if (piece < base + blk_total) {
-        const int excl = base + incl - parts;
-        const unsigned long long hit = __ballot(piece >= excl && piece < excl + parts);  // one lane: parts >= 1
-        const int src = __ffsll((long long)hit) - 1;
-        row = r0 + src;
-        split = piece - __builtin_amdgcn_readlane(excl, src);
-        n_parts = __builtin_amdgcn_readlane(parts, src);
-        flat_seq = __builtin_amdgcn_readlane(s, src);
-        flat_req = __builtin_amdgcn_readlane(r0 == 0 ? req0 : req_of(r0 + lane), src);
-        break;
+    // Rounding up per request can leave up to `rows` pieces more than wanted: a few CUs would
+    // then hold one workgroup more than the others and finish a quarter later (ragged batches:
+    // 18 % on the step).  The search below also counts the batch's pieces; while there are more
+    // than `want`, the pieces are lengthened and the search repeated.
+    for (int it = 0; it < 4; ++it) {
+      int base = 0;
+      row = -1;
+      for (int r0 = 0; r0 < a.rows; r0 += 64) {
+        const int s = r0 == 0 ? len0 : len_of(r0 + lane);
+        const int parts = r0 + lane < a.rows ? min(a.n_splits, max(1, (s + piece_len - 1) / piece_len)) : 0;
+        const int incl = wave_inclusive_scan<ScanAdd>(parts);
+        const int blk_total = __builtin_amdgcn_readlane(incl, 63);
+        if (row < 0 && piece < base + blk_total) {
+          const int excl = base + incl - parts;
+          const unsigned long long hit = __ballot(piece >= excl && piece < excl + parts);  // one lane: parts >= 1
+          const int src = __ffsll((long long)hit) - 1;
+          row = r0 + src;
+          split = piece - __builtin_amdgcn_readlane(excl, src);
+          n_parts = __builtin_amdgcn_readlane(parts, src);
+          flat_seq = __builtin_amdgcn_readlane(s, src);
+          flat_req = __builtin_amdgcn_readlane(r0 == 0 ? req0 : req_of(r0 + lane), src);
+        }
+        base += blk_total;
       }
-      base += blk_total;
+      if (base <= want || it == 3) break;
+      piece_len = (int)(((int64_t)piece_len * base + want - 1) / want);
+      piece_len = (piece_len + kTile - 1) / kTile * kTile;
     }
     if (row < 0) return;  // past the batch's last piece
   }
