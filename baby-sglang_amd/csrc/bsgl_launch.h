@@ -51,6 +51,10 @@ struct DecodeArgs {
   // (and no row more than n_splits); needs the in-kernel merge.  0: n_splits equal
   // pieces per row.
   int32_t balance_target;
+  // matrix-core kernel, set by the host layer together with n_kv_heads = 1 and head_dim = 128 when
+  // a model with two kv heads of 64 values is streamed as one 128-wide kv head: q heads per REAL kv
+  // head (0 = not folded)
+  int32_t fold_group;
   // fused KV write of the new token of each row (decode only); new_loc == NULL disables it
   const void* k_new;
   const void* v_new;

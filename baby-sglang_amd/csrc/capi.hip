@@ -79,11 +79,26 @@ int run_decode(bsgl::DecodeArgs& a, int32_t variant, uint32_t* counters, hipStre
   const bool may_fuse_kv = (variant & BSGL_DECODE_FUSE_KV_WRITE) != 0;
   const bool uniform_splits = (variant & BSGL_DECODE_UNIFORM_SPLITS) != 0;
   variant &= 0xff;
+  // Two kv heads of 64 values (Qwen2.5-0.5B): their rows are neighbours in a slab row and in the
+  // new-token rows, so the matrix-core kernel can stream the pair as ONE 128-wide kv head for all
+  // q heads (at most 16), with the in-kernel merge (its partial rows are 128 wide).
+  bsgl::DecodeArgs folded = a;
+  bool can_fold = false;
+  if (a.head_dim == 64 && a.n_kv_heads == 2 && a.n_q_heads % 2 == 0 && a.n_q_heads <= 16 &&
+      (counters != nullptr || bsgl::decode_direct_out(a)) && env_int("BSGL_NO_FOLD", 0) == 0) {
+    folded.fold_group = a.n_q_heads / 2;
+    folded.n_kv_heads = 1;
+    folded.head_dim = 128;
+    can_fold = bsgl::decode_mfma_supported(folded, &why);
+  }
   if (variant == BSGL_DECODE_MFMA) {
-    if (!bsgl::decode_mfma_supported(a, &why)) return fail(BSGL_ERR_UNSUPPORTED, "MFMA decode: %s", why);
+    if (can_fold) a = folded;
+    else if (!bsgl::decode_mfma_supported(a, &why)) return fail(BSGL_ERR_UNSUPPORTED, "MFMA decode: %s", why);
     use_mfma = true;
   } else if (variant == BSGL_DECODE_AUTO) {
-    use_mfma = bsgl::decode_mfma_supported(a, &why);
+    // (measured: below 32 requests the generic kernel is faster for this shape -- its merge is lighter)
+    if (can_fold && a.rows >= 32) a = folded;
+    use_mfma = a.fold_group > 0 || bsgl::decode_mfma_supported(a, &why);
   } else if (variant != BSGL_DECODE_VALU) {
     return fail(BSGL_ERR_BAD_ARG, "unknown decode variant %d", variant);
   }
@@ -116,12 +131,18 @@ int run_decode(bsgl::DecodeArgs& a, int32_t variant, uint32_t* counters, hipStre
   // one ticket per (row, kv head): fall back to the merge kernel when they do not fit
   const bool tickets_fit = (size_t)a.rows * (size_t)a.n_kv_heads * 4 <= kCounterBytes &&
                            (size_t)a.n_splits * a.rows * a.n_q_heads * a.head_dim * 4 < (1ull << 31);
-  a.counters = (use_mfma && tickets_fit && env_int("BSGL_NO_FUSED_MERGE", 0) == 0) ? counters : nullptr;
+  a.counters = (use_mfma && tickets_fit && (a.fold_group > 0 || env_int("BSGL_NO_FUSED_MERGE", 0) == 0)) ? counters : nullptr;
+  if (a.fold_group > 0 && a.counters == nullptr && !bsgl::decode_direct_out(a))
+    return fail(BSGL_ERR_UNSUPPORTED, "folded kv heads need the in-kernel merge (batch too large for the ticket area)");
   // length-balanced pieces: needs the in-kernel merge (a row's piece count varies) and a
   // batch small enough for every workgroup to scan its seq_lens
   a.balance_target = 0;
   if (a.counters != nullptr && a.n_splits > 1 && a.rows <= 1024 && a.kv.table_cols <= (1 << 20) && !uniform_splits && env_int("BSGL_DECODE_BALANCE", 1) != 0)
     a.balance_target = (a.n_splits + 1) / 2;
+  // (folded heads: the workgroup that merges a request reads the partial rows of ALL its q heads,
+  // 14 for Qwen2.5-0.5B: more than 8 pieces per request cost more in that merge than they gain)
+  // -- and with half as many kv heads to cut, up to n_splits pieces are wanted below that
+  if (a.fold_group > 0 && a.balance_target > 0) a.balance_target = a.n_splits < 8 ? a.n_splits : 8;
   const hipError_t e = use_mfma ? bsgl::launch_decode_mfma(a, stream) : bsgl::launch_decode_valu(a, stream);
   if (e != hipSuccess) return hip_fail("decode launch", e);
   return BSGL_OK;
@@ -206,11 +227,15 @@ int32_t bsgl_decode_num_splits(int32_t batch, int32_t n_kv_heads, int32_t max_co
 
 size_t bsgl_decode_counter_bytes(void) { return kCounterBytes; }
 
+// partial output rows in the decode workspace: head_dim floats, but never fewer than 128 (two kv
+// heads of 64 values may run folded into one 128-wide head)
+static size_t partial_row_width(int32_t head_dim) { return head_dim < 128 ? 128 : (size_t)head_dim; }
+
 size_t bsgl_decode_workspace_bytes(int32_t batch, int32_t n_q_heads, int32_t head_dim, int32_t n_splits,
                                    int32_t out_is_f32) {
   if (batch <= 0 || n_splits < 1 || (n_splits == 1 && !out_is_f32)) return 0;
   const size_t rh = (size_t)batch * (size_t)n_q_heads;
-  return kCounterBytes + align_up((size_t)n_splits * rh * (size_t)head_dim * 4, 256) +
+  return kCounterBytes + align_up((size_t)n_splits * rh * (size_t)partial_row_width(head_dim) * 4, 256) +
          align_up((size_t)n_splits * rh * 4, 256);
 }
 
@@ -271,7 +296,7 @@ int bsgl_paged_decode(void* out, int64_t out_row_stride, float* lse, const void*
   const size_t rh = (size_t)batch * (size_t)n_q_heads;
   const size_t cb = kCounterBytes;
   a.ws_o = need ? (float*)((char*)workspace + cb) : nullptr;
-  a.ws_lse = need ? (float*)((char*)workspace + cb + align_up((size_t)n_splits * rh * (size_t)head_dim * 4, 256)) : nullptr;
+  a.ws_lse = need ? (float*)((char*)workspace + cb + align_up((size_t)n_splits * rh * partial_row_width(head_dim) * 4, 256)) : nullptr;
   return run_decode(a, variant, need ? (uint32_t*)workspace : nullptr, (hipStream_t)stream);
 }
 

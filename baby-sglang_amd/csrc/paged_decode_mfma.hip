@@ -164,6 +164,12 @@ void decode_mfma_kernel(DecodeArgs a) {
   }
   const int head0 = hg * HPT;
   const int G = a.n_q_heads / a.n_kv_heads;
+  // Folded heads (fold_group > 0): the caller's model has two kv heads of 64 values; their rows
+  // stand side by side in a slab row, so the pair is streamed as ONE 128-wide kv head serving all
+  // q heads.  q head h belongs to kv head h / fold_group: its query is zero outside that half of
+  // the row (the scores are then exactly the 64-wide ones) and only that half of its output row
+  // is kept.  Partial results stay 128 wide.
+  const int fold = a.fold_group;
   const int lq = lane & 15;   // q head (column of S^T / row of O) or d column
   const int lg = lane >> 4;   // lane group
 
@@ -197,7 +203,12 @@ void decode_mfma_kernel(DecodeArgs a) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         qf[hh][s] = make_uint4(0, 0, 0, 0);
-        if (lq < G) qf[hh][s] = *(const uint4*)(qrow + (((int64_t)(head0 + hh) * G + lq) * D + 32 * s + 8 * lg) * 2);
+        if (fold == 0) {
+          if (lq < G) qf[hh][s] = *(const uint4*)(qrow + (((int64_t)(head0 + hh) * G + lq) * D + 32 * s + 8 * lg) * 2);
+        } else if (lq < G && (32 * s + 8 * lg) / 64 == lq / fold) {
+          // folded heads: q head lq's 64 values stand in the half of the 128-wide row that its kv head owns
+          qf[hh][s] = *(const uint4*)(qrow + ((int64_t)lq * 64 + (32 * s + 8 * lg) % 64) * 2);
+        }
       }
   }
   const float scale_log2e = a.scale * kLog2e;
@@ -391,9 +402,17 @@ void decode_mfma_kernel(DecodeArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int q = 4 * lg + r;
         if (q < G) {
-          char* orow = (char*)a.out + ((int64_t)row * a.out_row_stride + (int64_t)(hq0 + q) * D) * 2;
+          if (fold == 0) {
+            char* orow = (char*)a.out + ((int64_t)row * a.out_row_stride + (int64_t)(hq0 + q) * D) * 2;
 #pragma unroll
-          for (int n = 0; n < 8; ++n) *(uint16_t*)(orow + (16 * n + lq) * 2) = (uint16_t)E::pack2(o_acc[hh][n][r] * ir[r], 0.f);
+            for (int n = 0; n < 8; ++n) *(uint16_t*)(orow + (16 * n + lq) * 2) = (uint16_t)E::pack2(o_acc[hh][n][r] * ir[r], 0.f);
+          } else {
+            char* orow = (char*)a.out + ((int64_t)row * a.out_row_stride + (int64_t)q * 64) * 2;
+            const int half = q / fold;
+#pragma unroll
+            for (int n = 0; n < 8; ++n)
+              if (n / 4 == half) *(uint16_t*)(orow + (16 * (n % 4) + lq) * 2) = (uint16_t)E::pack2(o_acc[hh][n][r] * ir[r], 0.f);
+          }
         }
       }
       continue;
@@ -491,10 +510,14 @@ void decode_mfma_kernel(DecodeArgs a) {
       if (h0 + j >= nh) break;
       const float inv = wsum[j] > 0.f ? 1.f / wsum[j] : 0.f;
       const int64_t hq = (int64_t)head0 * G + h0 + j;
-      if (a.out_dtype == kF32) {
-        *(float2*)((char*)a.out + ((int64_t)row * a.out_row_stride + hq * D + lane * 2) * 4) = make_float2(acc[j][0] * inv, acc[j][1] * inv);
+      // (folded heads: lanes holding the other kv head's half of the row do not store)
+      const bool keep = fold == 0 || (lane * 2) / 64 == (int)hq / fold;
+      const int64_t col = fold == 0 ? hq * D + lane * 2 : hq * 64 + (lane * 2) % 64;
+      if (!keep) {
+      } else if (a.out_dtype == kF32) {
+        *(float2*)((char*)a.out + ((int64_t)row * a.out_row_stride + col) * 4) = make_float2(acc[j][0] * inv, acc[j][1] * inv);
       } else {
-        *(uint32_t*)((char*)a.out + ((int64_t)row * a.out_row_stride + hq * D + lane * 2) * 2) = E::pack2(acc[j][0] * inv, acc[j][1] * inv);
+        *(uint32_t*)((char*)a.out + ((int64_t)row * a.out_row_stride + col) * 2) = E::pack2(acc[j][0] * inv, acc[j][1] * inv);
       }
       if (a.lse != nullptr && lane == 0)
         a.lse[rh0 + h0 + j] = wsum[j] > 0.f ? mx[j] + __builtin_amdgcn_logf(wsum[j]) * kLn2 : kNegInf;

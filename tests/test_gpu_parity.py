@@ -188,6 +188,51 @@ def test_decode_random_ragged(gpu, dtype, hq, hkv, dim, variant):
         assert torch.allclose(lse.double().cpu(), want_lse, rtol=1e-4, atol=2e-3 if dtype != torch.float32 else 1e-4)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hq", [14, 4, 16])
+def test_two_kv_heads_of_64_on_the_matrix_core_kernel(gpu, dtype, hq):
+    """Two kv heads of 64 values (Qwen2.5-0.5B: 14 q heads) streamed as one 128-wide kv head:
+    forced matrix-core variant (the automatic choice only folds from 32 requests on) against the
+    float64 oracle, with the new token's rows written by the kernel, f32 output + lse, every
+    split count incl. the unsplit direct path, and a batch large enough for the automatic choice."""
+    from baby_sglang_amd import _hip
+
+    hkv, dim = 2, 64
+    seq_lens = [1, 2, 63, 64, 65, 300, 1025, 7, 128, 129, 511]
+    cpu, r2t, kv = random_decode_problem(gpu, dtype, hq, hkv, dim, seq_lens, seed=hq * 100 + dim)
+    rows, seq = cpu["req_pool_indices"].to(gpu), cpu["seq_lens"].to(gpu)
+    gen = torch.Generator().manual_seed(8)
+    k_new = torch.randn((len(seq_lens), hkv, dim), generator=gen).to(dtype)
+    v_new = torch.randn((len(seq_lens), hkv, dim), generator=gen).to(dtype)
+    loc = r2t.req_to_token[rows, seq - 1].contiguous()
+    k_ref, v_ref = cpu["k_slab"].clone(), cpu["v_slab"].clone()
+    orc.kv_scatter_ref(k_ref, v_ref, loc.cpu(), k_new, v_new)
+    want, want_lse = orc.decode_exact(cpu["q"], k_ref, v_ref, cpu["req_to_token"], cpu["req_pool_indices"],
+                                      cpu["seq_lens"], return_lse=True)
+    for n_splits in (1, 3, 16):
+        kv.k_buffer[0].copy_(cpu["k_slab"])
+        kv.v_buffer[0].copy_(cpu["v_slab"])
+        k_slab, v_slab = kv.get_kv_buffer(0)
+        out = _hip.paged_decode(cpu["q"].to(gpu), k_slab, v_slab, r2t.req_to_token, rows, seq, n_splits=n_splits, variant=2,
+                                k_new=k_new.to(gpu), v_new=v_new.to(gpu), out_cache_loc=loc, fuse_kv_write=True)
+        assert_close(out, want, dtype, f"folded heads, splits={n_splits}")
+        assert torch.equal(k_slab.cpu(), k_ref) and torch.equal(v_slab.cpu(), v_ref)
+        lse = torch.empty((len(seq_lens), hq), dtype=torch.float32, device=gpu)
+        out32 = _hip.paged_decode(cpu["q"].to(gpu), k_slab, v_slab, r2t.req_to_token, rows, seq, n_splits=n_splits, variant=2,
+                                  lse=lse, out_dtype=torch.float32)
+        assert out32.dtype == torch.float32
+        assert_close(out32, want, dtype, f"folded heads f32 out, splits={n_splits}")
+        assert torch.allclose(lse.double().cpu(), want_lse, rtol=1e-4, atol=2e-3)
+    # 40 requests: the automatic choice folds as well; same answer as the generic kernel's
+    seq_lens = [17 + 13 * i for i in range(40)]
+    cpu, r2t, kv = random_decode_problem(gpu, dtype, hq, hkv, dim, seq_lens, seed=3)
+    want = orc.decode_exact(cpu["q"], cpu["k_slab"], cpu["v_slab"], cpu["req_to_token"], cpu["req_pool_indices"], cpu["seq_lens"])
+    k_slab, v_slab = kv.get_kv_buffer(0)
+    args = (cpu["q"].to(gpu), k_slab, v_slab, r2t.req_to_token, cpu["req_pool_indices"].to(gpu), cpu["seq_lens"].to(gpu))
+    assert_close(_hip.paged_decode(*args), want, dtype, "folded heads, automatic")
+    assert_close(_hip.paged_decode(*args, variant=1), want, dtype, "generic kernel")
+
+
 @pytest.mark.parametrize("dtype,hq,hkv", [(torch.bfloat16, 12, 2), (torch.float16, 28, 4), (torch.bfloat16, 6, 1)])
 def test_fused_kv_write_and_merge(gpu, dtype, hq, hkv, monkeypatch):
     """The decode kernel that stores the new token itself and merges its own
