@@ -388,6 +388,14 @@ int bsgl_paged_prefill(void* out, int64_t out_row_stride, const void* q, int64_t
   const int32_t kind = variant & 0xff;
   if (kind != BSGL_DECODE_AUTO && kind != BSGL_DECODE_VALU && kind != BSGL_DECODE_MFMA)
     return fail(BSGL_ERR_BAD_ARG, "unknown variant %d", variant);
+  // two kv heads of 64 values (Qwen2.5-0.5B): streamed as one 128-wide kv head (see run_decode)
+  if (head_dim == 64 && n_kv_heads == 2 && n_q_heads % 2 == 0 && n_q_heads <= 16 && env_int("BSGL_NO_FOLD", 0) == 0) {
+    bsgl::PrefillArgs folded = pa;
+    folded.fold_group = n_q_heads / 2;
+    folded.n_kv_heads = 1;
+    folded.head_dim = 128;
+    if (bsgl::prefill_mfma_supported(folded, &why)) pa = folded;
+  }
   const bool mfma_ok = bsgl::prefill_mfma_supported(pa, &why);
   if (kind == BSGL_DECODE_MFMA && !mfma_ok) return fail(BSGL_ERR_UNSUPPORTED, "matrix-core extend: %s", why);
   if (kind != BSGL_DECODE_VALU && mfma_ok) {

@@ -77,6 +77,11 @@ void prefill_mfma_kernel(PrefillArgs a) {
   const int lq = lane & 15;  // query position inside the wave's 16 (column of S^T, row of O)
   const int lg = lane >> 4;
   const int G = a.n_q_heads / a.n_kv_heads;
+  // Folded heads (fold_group > 0, set by the host layer with n_kv_heads = 1 and head_dim = 128): two
+  // kv heads of 64 values, neighbours in a slab row, streamed as one 128-wide kv head.  q head h
+  // belongs to kv head h / fold_group: its query is zero outside that half of the row and only that
+  // half of its output row is written.
+  const int fold = a.fold_group;
 
   // ---- which (request, block of 16 * WAVES positions, kv head, q-head slice) is this? -------
   // Workgroups are dealt to the 8 XCDs round-robin by launch index, and each XCD has its own
@@ -139,7 +144,14 @@ void prefill_mfma_kernel(PrefillArgs a) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         qf[rt][s] = make_uint4(0, 0, 0, 0);
-        if (lq < n_rows && rt < n_rt) qf[rt][s] = *(const uint4*)(qrow + (((int64_t)kvh * G + rt0 + rt) * D + 32 * s + 8 * lg) * 2);
+        if (lq < n_rows && rt < n_rt) {
+          if (fold == 0) {
+            qf[rt][s] = *(const uint4*)(qrow + (((int64_t)kvh * G + rt0 + rt) * D + 32 * s + 8 * lg) * 2);
+          } else if ((32 * s + 8 * lg) / 64 == (rt0 + rt) / fold) {
+            // folded heads: the 64 values of q head h stand in the half of the 128-wide row that its kv head owns
+            qf[rt][s] = *(const uint4*)(qrow + ((int64_t)(rt0 + rt) * 64 + (32 * s + 8 * lg) % 64) * 2);
+          }
+        }
       }
   }
   const float scale_log2e = a.scale * kLog2e;
@@ -358,7 +370,11 @@ void prefill_mfma_kernel(PrefillArgs a) {
       const float* src = o_lds + r * kOPad + c8 * 8;
       const uint4 packed = make_uint4(E::pack2(src[0], src[1]), E::pack2(src[2], src[3]),
                                       E::pack2(src[4], src[5]), E::pack2(src[6], src[7]));
-      *(uint4*)((char*)a.out + ((q_row0 + r) * a.out_row_stride + head * D + c8 * 8) * 2) = packed;
+      if (fold == 0) {
+        *(uint4*)((char*)a.out + ((q_row0 + r) * a.out_row_stride + head * D + c8 * 8) * 2) = packed;
+      } else if ((c8 * 8) / 64 == (int)head / fold) {
+        *(uint4*)((char*)a.out + ((q_row0 + r) * a.out_row_stride + head * 64 + (c8 * 8) % 64) * 2) = packed;
+      }
     }
   }
 }
@@ -409,7 +425,7 @@ bool prefill_mfma_supported(const PrefillArgs& a, const char** why) {
     *why = "matrix-core extend needs head_dim 128";
     return false;
   }
-  if (a.n_kv_heads <= 0 || a.n_q_heads % a.n_kv_heads != 0 || a.n_q_heads / a.n_kv_heads > 8) {
+  if (a.n_kv_heads <= 0 || a.n_q_heads % a.n_kv_heads != 0 || a.n_q_heads / a.n_kv_heads > (a.fold_group > 0 ? 16 : 8)) {
     *why = "matrix-core extend needs 1..8 query heads per kv head";
     return false;
   }

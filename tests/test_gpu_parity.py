@@ -472,14 +472,15 @@ def test_prefill_random(gpu):
         assert_close(out, want, dtype, f"prefill {dtype}")
 
 
-@pytest.mark.parametrize("dtype,hq,hkv", [(torch.bfloat16, 12, 2), (torch.float16, 28, 4), (torch.bfloat16, 8, 1), (torch.float16, 5, 5)])
+@pytest.mark.parametrize("dtype,hq,hkv", [(torch.bfloat16, 12, 2), (torch.float16, 28, 4), (torch.bfloat16, 8, 1), (torch.float16, 5, 5),
+                                          (torch.bfloat16, 14, 2), (torch.float16, 14, 2), (torch.float16, 4, 2)])
 def test_prefill_kernels_agree(gpu, dtype, hq, hkv):
     """Matrix-core extend kernel vs the generic one vs the float64 oracle: block
     boundaries (15/16/17 rows), long prefixes, several slot blocks, chunked prefill
     (a chunk is an extend over the request's own earlier chunks)."""
     from baby_sglang_amd import _hip
 
-    dim = 128
+    dim = 64 if (hq, hkv) in ((14, 2), (4, 2)) else 128  # (two kv heads of 64: folded into one of 128)
     seq_lens = [16, 15, 17, 700, 1100, 33, 1]
     prefix_lens = [0, 0, 0, 512, 1024, 32, 0]
     cpu, r2t, kv = random_decode_problem(gpu, dtype, hq, hkv, dim, seq_lens, seed=hq + 7)

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--prefix", type=int, default=1536)
     ap.add_argument("--hq", type=int, default=28)
     ap.add_argument("--hkv", type=int, default=4)
+    ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--table", default="perm")
@@ -30,7 +31,7 @@ def main():
     import baby_sglang_amd as pkg
 
     dev = torch.device("cuda:0")
-    dim, dtype = 128, torch.bfloat16 if a.dtype == "bf16" else torch.float16
+    dim, dtype = a.dim, torch.bfloat16 if a.dtype == "bf16" else torch.float16
     seq = a.prefix + a.ext
     size = a.batch * seq
     gen = torch.Generator(device=dev).manual_seed(0)
