@@ -544,6 +544,53 @@ def test_extend_scores_rising_along_the_sequence(gpu, dtype, slope):
     assert bool(torch.isfinite(got).all()) and bool((err <= bound).all()), f"worst excess {(err - bound).max().item():.3e}"
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_random_shapes_against_the_oracle(gpu, seed):
+    """Random model shapes, dtypes, batch sizes, lengths, prefixes, split counts and KV layouts:
+    decode (new rows written by the call) and extend through the automatic kernel choice, against
+    the float64 oracle; KV rows bit exact."""
+    from baby_sglang_amd import _hip
+
+    gen = torch.Generator().manual_seed(900 + seed)
+
+    def pick(options):
+        return options[int(torch.randint(0, len(options), (1,), generator=gen))]
+
+    hq, hkv, dim = pick([(12, 2, 128), (14, 2, 64), (28, 4, 128), (4, 4, 64), (8, 1, 128), (16, 2, 64), (7, 1, 128), (16, 2, 128)])
+    dtype = pick([torch.bfloat16, torch.float16, torch.float32])
+    layout = pick(["interleaved", "split"])
+    batch = pick([1, 2, 5, 33, 70])
+    seq_lens = [int(n) for n in torch.randint(1, pick([40, 300, 1400]), (batch,), generator=gen)]
+    cpu, r2t, kv = random_decode_problem(gpu, dtype, hq, hkv, dim, seq_lens, seed=seed, layout=layout)
+    rows, seq = cpu["req_pool_indices"].to(gpu), cpu["seq_lens"].to(gpu)
+    k_slab, v_slab = kv.get_kv_buffer(0)
+    # decode with the step's new rows
+    k_new = torch.randn((batch, hkv, dim), generator=gen).to(dtype)
+    v_new = torch.randn((batch, hkv, dim), generator=gen).to(dtype)
+    loc = r2t.req_to_token[rows, seq - 1].contiguous()
+    k_ref, v_ref = cpu["k_slab"].clone(), cpu["v_slab"].clone()
+    orc.kv_scatter_ref(k_ref, v_ref, loc.cpu(), k_new, v_new)
+    want = orc.decode_exact(cpu["q"], k_ref, v_ref, cpu["req_to_token"], cpu["req_pool_indices"], cpu["seq_lens"])
+    n_splits = pick([None, 1, 2, 7, 32])
+    out = _hip.paged_decode(cpu["q"].to(gpu), k_slab, v_slab, r2t.req_to_token, rows, seq, n_splits=n_splits,
+                            k_new=k_new.to(gpu), v_new=v_new.to(gpu), out_cache_loc=loc, fuse_kv_write=pick([True, False]))
+    assert_close(out, want, dtype, f"decode {hq}/{hkv}/{dim} {dtype} batch {batch} splits {n_splits} {layout}")
+    assert torch.equal(k_slab.cpu(), k_ref) and torch.equal(v_slab.cpu(), v_ref)
+    # extend of the same requests over random prefixes
+    prefix = [int(torch.randint(0, n, (1,), generator=gen)) if n > 1 and pick([True, False]) else 0 for n in seq_lens]
+    ext = [n - p for n, p in zip(seq_lens, prefix)]
+    q = torch.randn((sum(ext), hq, dim), generator=gen).to(dtype)
+    pl, el = torch.tensor(prefix), torch.tensor(ext)
+    want = orc.prefill_exact(q, k_ref, v_ref, cpu["req_to_token"], cpu["req_pool_indices"], cpu["seq_lens"], pl, el)
+    got = _hip.paged_prefill(q.to(gpu), k_slab, v_slab, r2t.req_to_token, rows, seq, pl.to(gpu), el.to(gpu))
+    if dtype == torch.bfloat16:  # (probabilities rounded once: bound by the rounding of the terms, as above)
+        spread = orc.prefill_exact(q, k_ref, v_ref.abs(), cpu["req_to_token"], cpu["req_pool_indices"], cpu["seq_lens"], pl, el)
+        err = (got.double().cpu() - want).abs()
+        assert bool((err <= 2.0**-8 * want.abs() + 2.0**-8 * spread + 1e-4).all()), f"extend {hq}/{hkv}/{dim} batch {batch}"
+    else:
+        assert_close(got, want, dtype, f"extend {hq}/{hkv}/{dim} {dtype} batch {batch} {layout}")
+
+
 def test_side_stream_and_thread(gpu):
     """The reference calls its backend from a worker thread inside a side stream
     (overlap_worker.py:104-127); results must not depend on either."""

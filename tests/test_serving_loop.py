@@ -191,3 +191,46 @@ def test_overlap_mode_gives_the_same_ids(name):
     # and again on the same loop, now with the prompts in the prefix tree
     assert [list(o) for o in loop.run_batch_overlap(sc["prompts"], sp)] == [o.tolist() for o in sc["output_ids"]]
     assert [list(o) for o in loop.run_batch(sc["prompts"], sp)] == [o.tolist() for o in sc["output_ids"]]
+
+
+def _expected(prompt, n_new, vocab, eos):
+    """What the stand-in model makes of a prompt: each id is a function of the id before it and its position."""
+    ids, last, pos = [], int(prompt[-1]), len(prompt) - 1
+    for _ in range(n_new):
+        last = (7 * last + 3 * pos + 1) % vocab
+        pos += 1
+        ids.append(last)
+        if eos != -1 and last == eos:
+            break
+    return ids
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_streams_in_every_mode(seed):
+    """Random request streams (shared prefixes of random depth, repeated prompts, tight pools that
+    force eviction, eos on or off): step-by-step, chunked and overlapped loops all give what the
+    stand-in model defines request by request, and hand every row and slot back."""
+    gen = torch.Generator().manual_seed(100 + seed)
+    vocab = 31
+    rows = int(torch.randint(2, 6, (1,), generator=gen))
+    ctx = int(torch.randint(40, 64, (1,), generator=gen))
+    n_new = int(torch.randint(1, 9, (1,), generator=gen))
+    eos = int(torch.randint(0, vocab, (1,), generator=gen)) if seed % 2 else -1
+    stems = [torch.randint(0, vocab, (int(torch.randint(4, 20, (1,), generator=gen)),), generator=gen) for _ in range(3)]
+    prompts = []
+    for _ in range(int(torch.randint(6, 14, (1,), generator=gen))):
+        stem = stems[int(torch.randint(0, 3, (1,), generator=gen))]
+        keep = int(torch.randint(1, len(stem) + 1, (1,), generator=gen))
+        tail = torch.randint(0, vocab, (int(torch.randint(0, 12, (1,), generator=gen)),), generator=gen)
+        prompts.append(torch.cat([stem[:keep], tail]))
+    prompts.append(prompts[0].clone())  # an exact repeat
+    want = [_expected(p.tolist(), n_new, vocab, eos) for p in prompts]
+    sp = SamplingParams(max_new_tokens=n_new, eos_id=eos)
+    for mode in ("plain", "chunked", "overlap"):
+        loop = ServingLoop(StandInModel(vocab), max_total_tokens=rows * ctx, max_requests=rows,
+                           chunked_prefill_size=5 if mode == "chunked" else None)
+        for _ in range(2):  # the second pass runs against a warm prefix tree
+            outs = (loop.run_batch_overlap if mode == "overlap" else loop.run_batch)(prompts, sp)
+            assert [list(o) for o in outs] == want, (mode, seed)
+            assert loop.req_to_token_pool.available_size() == rows
+            assert loop.token_to_kv_pool.available_size() + loop.tree_cache.evictable_size() == rows * ctx
