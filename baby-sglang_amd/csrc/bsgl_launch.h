@@ -127,7 +127,7 @@ struct PrefillArgs {
   int32_t blk_rows;    // query positions per workgroup: 16 or 64
   int32_t grp_blocks;  // consecutive blocks of a request that form one group (share an XCD)
   int32_t max_groups;  // bound on cu_blk[batch]
-  uint64_t* prof;      // tuning aid, normally NULL: 6 x uint64 of phase cycles per wave
+  uint64_t* prof;      // tuning aid, normally NULL: 8 x uint64 of phase cycles per wave
   int32_t fold_group;  // two kv heads of 64 values streamed as one of 128 (see DecodeArgs::fold_group); 0 = no
   int32_t n_q_heads;
   int32_t n_kv_heads;

@@ -65,13 +65,15 @@ void prefill_mfma_kernel(PrefillArgs a) {
   constexpr int kOPad = D + 4;
   constexpr int STAGE_OUT = 16 * kOPad * 4;        // output staging of one wave
   constexpr int BUF = RING > WAVES * STAGE_OUT ? RING : WAVES * STAGE_OUT;
-  static_assert(DMA_PER_STEP % WAVES == 0 && kSlotBlock % STEP == 0, "");
+  constexpr int SLOTS = kSlotBlock;  // page-table entries staged in LDS at a time (4096 was measured: no faster)
+  static_assert(DMA_PER_STEP % WAVES == 0 && SLOTS % STEP == 0, "");
 
-  __shared__ __attribute__((aligned(1024))) char smem[BUF + kSlotBlock * 4];
+  __shared__ __attribute__((aligned(1024))) char smem[BUF + SLOTS * 4];
   int32_t* s_slots = (int32_t*)(smem + BUF);
   const uint32_t lds_ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
   const int tid = threadIdx.x;
+  const uint64_t t_entry = a.prof != nullptr ? __builtin_readcyclecounter() : 0;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lq = lane & 15;  // query position inside the wave's 16 (column of S^T, row of O)
@@ -176,7 +178,7 @@ void prefill_mfma_kernel(PrefillArgs a) {
   // tuning aid: cycles this wave spent waiting for its DMA, at the barrier, issuing DMA, in
   // the score / softmax half and in the PV half of its steps, and the step count
   const bool PROF = a.prof != nullptr;
-  uint64_t prof[6] = {0, 0, 0, 0, 0, 0};
+  uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   float m_run[RT], neg_mc[RT];  // reference score of the lane's row, and -(that) * scale * log2(e)
   constexpr float kSlack = 6.f;
   const float slack_raw = kSlack / scale_log2e;
@@ -193,8 +195,8 @@ void prefill_mfma_kernel(PrefillArgs a) {
     for (int n = 0; n < 8; ++n) o_acc[rt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  for (int blk = 0; blk < kv_len; blk += kSlotBlock) {
-    const int n_blk = min(kSlotBlock, kv_len - blk);
+  for (int blk = 0; blk < kv_len; blk += SLOTS) {
+    const int n_blk = min(SLOTS, kv_len - blk);
     const int n_steps = (n_blk + STEP - 1) / STEP;
     __syncthreads();  // every wave is done with the previous block's offsets and tiles
     for (int i = tid; i < n_blk; i += 64 * WAVES) {
@@ -227,6 +229,7 @@ void prefill_mfma_kernel(PrefillArgs a) {
       }
     };
 
+    if (PROF && blk == 0) prof[6] = __builtin_readcyclecounter() - t_entry;  // kernel entry -> first request for K/V
     issue_step(0);
     if (n_steps > 1) issue_step(1);
 
@@ -347,11 +350,7 @@ void prefill_mfma_kernel(PrefillArgs a) {
     }
   }
 
-  if (PROF && lane == 0) {
-    uint64_t* dst = a.prof + 6 * ((uint64_t)blockIdx.x * WAVES + wave);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) dst[i] = prof[i];
-  }
+  const uint64_t t_loop_end = PROF ? __builtin_readcyclecounter() : 0;
   // ---- normalise and write: rows through LDS so that a lane stores 16 contiguous bytes ----
   __syncthreads();  // the ring is free: each wave stages its rows in its own region
   float* o_lds = (float*)(smem + wave * STAGE_OUT);
@@ -376,6 +375,13 @@ void prefill_mfma_kernel(PrefillArgs a) {
         *(uint4*)((char*)a.out + ((q_row0 + r) * a.out_row_stride + head * 64 + (c8 * 8) % 64) * 2) = packed;
       }
     }
+  }
+  if (PROF && lane == 0) {
+    prof[7] = __builtin_readcyclecounter() - t_entry;       // the wave's whole life
+    prof[6] |= (uint64_t)(prof[7] - (t_loop_end - t_entry)) << 32;  // high half: after the last step (normalise, store)
+    uint64_t* dst = a.prof + 8 * ((uint64_t)blockIdx.x * WAVES + wave);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[i] = prof[i];
   }
 }
 

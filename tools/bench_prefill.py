@@ -74,13 +74,14 @@ def main():
 
     if a.profile:
         n_wave = 1 << 20
-        buf = torch.zeros((n_wave, 6), dtype=torch.int64, device=dev)
+        buf = torch.zeros((n_wave, 8), dtype=torch.int64, device=dev)
         pkg._hip.lib.bsgl_debug_prefill_profile(buf.data_ptr())
         call()
         torch.cuda.synchronize()
         pkg._hip.lib.bsgl_debug_prefill_profile(None)
-        t = buf.cpu()
-        t = t[t[:, 5] > 0].double()
+        ti = buf.cpu()
+        ti = ti[ti[:, 7] > 0]
+        t = ti.double()
         steps = t[:, 5].sum()
         names = ("own-DMA wait", "barrier", "DMA issue", "score+softmax", "PV")
         tot = t[:, :5].sum()
@@ -88,6 +89,12 @@ def main():
         for i, n in enumerate(names):
             print(f"    {n:14s} {t[:, i].sum() / steps:8.0f}  ({t[:, i].sum() / tot:6.1%})")
         print(f"    {'sum':14s} {tot / steps:8.0f}")
+        pro = ti[:, 6] & 0xFFFFFFFF
+        epi = ti[:, 6] >> 32
+        life = t[:, 7]
+        print(f"  per wave: whole life {life.mean():.0f} cycles = before the first K/V request {pro.double().mean():.0f} "
+              f"+ steps {t[:, :5].sum(1).mean():.0f} + after the last step {epi.double().mean():.0f} "
+              f"+ rest {life.mean() - pro.double().mean() - t[:, :5].sum(1).mean() - epi.double().mean():.0f}")
 
 
 if __name__ == "__main__":
