@@ -104,12 +104,16 @@ void prefill_mfma_kernel(PrefillArgs a) {
   const int64_t pg = g / a.n_kv_heads;       // (request, block group) index
   const int rt0 = (within % n_z) * RT;       // first q head of the group handled here
   const int n_rt = min(RT, G - rt0);         // heads past it compute on zero queries and are not written
-  int lo = 0, hi = a.batch;  // last request with cu_blk[lo] <= pg
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (a.cu_blk[mid] <= pg) lo = mid; else hi = mid;
+  // the request that owns group pg: the last one with cu_blk[i] <= pg, i.e. the number of running
+  // sums cu_blk[1..batch] that do not exceed pg (64 compared per load, all loads independent: a
+  // binary search would be a chain of dependent loads at the head of every workgroup)
+  int i_req = 0;
+  for (int base = 1; base <= a.batch; base += 64) {
+    const int j = base + lane;
+    const bool le = j <= a.batch && a.cu_blk[j] <= pg;
+    i_req += __popcll(__ballot(le));
   }
-  const int i_req = lo;
+  i_req = min(i_req, a.batch - 1);
   const int64_t ext_raw = a.extended_lens[i_req];
   const int n_blocks = (int)(((ext_raw < 0 ? 0 : ext_raw) + 16 * WAVES - 1) / (16 * WAVES));
   const int bg0 = (int)(pg - a.cu_blk[i_req]) * a.grp_blocks;  // first block of the group
