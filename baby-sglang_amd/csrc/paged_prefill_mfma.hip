@@ -217,23 +217,26 @@ void prefill_mfma_kernel(PrefillArgs a) {
     // the block re-read its last one and are masked below
     auto issue_step = [&](int step) {
       const uint32_t stage = lds_ring + (uint32_t)(step % NSTAGE) * STEP_BYTES;
-      const uint32_t tok_off = (uint32_t)s_slots[min(step * STEP + (lane & 31), n_blk - 1)];
+      // each lane reads the row offsets of ITS tokens straight from the staged entries: instruction
+      // j of this wave moves tokens 2 i and 2 i + 1 (i = wave * DPW + j), the lower half of the
+      // lanes the first of them
+      uint32_t off[DPW];
+#pragma unroll
+      for (int j = 0; j < DPW; ++j)
+        off[j] = (uint32_t)s_slots[min(step * STEP + 2 * (wave * DPW + j) + lane_tok, n_blk - 1)];
 #pragma unroll
       for (int j = 0; j < DPW; ++j) {
         const int i = wave * DPW + j;  // wave-uniform
         const int t0 = 2 * (i & 7);
-        const uint32_t off0 = __builtin_amdgcn_readlane(tok_off, 2 * i);
-        const uint32_t off1 = __builtin_amdgcn_readlane(tok_off, 2 * i + 1);
         const uint32_t rec = (uint32_t)rec_of_token(t0);
         const uint32_t xr = (uint32_t)xr_of_rec((int)rec);
-        uint64_t src = ((uint64_t)(lane < 32 ? off0 : off1) << 4) + lane_src;
+        uint64_t src = ((uint64_t)off[j] << 4) + lane_src;
         src ^= (uint64_t)(xr << 4);
         dma_1k<false>((const void*)src,
                       __builtin_amdgcn_readfirstlane(stage + (uint32_t)(i >> 3) * TILE_BYTES + rec * REC));
       }
     };
 
-    if (PROF && blk == 0) prof[6] = __builtin_readcyclecounter() - t_entry;  // kernel entry -> first request for K/V
     issue_step(0);
     if (n_steps > 1) issue_step(1);
 
