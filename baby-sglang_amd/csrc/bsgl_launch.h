@@ -194,5 +194,9 @@ hipError_t launch_prefill_expand(const ExpandArgs& a, hipStream_t stream);
 
 bool prefill_mfma_supported(const PrefillArgs& a, const char** why);
 hipError_t launch_prefill_mfma(const PrefillArgs& a, hipStream_t stream);
+// the 32x32x16 form of the same kernel (64-position blocks, two or more q heads per kv head);
+// launch_prefill_mfma picks it where it applies
+bool prefill_mfma32_supported(const PrefillArgs& a);
+hipError_t launch_prefill_mfma32(const PrefillArgs& a, hipStream_t stream);
 
 }  // namespace bsgl

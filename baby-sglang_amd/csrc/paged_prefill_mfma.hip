@@ -202,6 +202,8 @@ void prefill_mfma_kernel(PrefillArgs a) {
   for (int blk = 0; blk < kv_len; blk += SLOTS) {
     const int n_blk = min(SLOTS, kv_len - blk);
     const int n_steps = (n_blk + STEP - 1) / STEP;
+    const uint64_t t_stage = PROF ? __builtin_readcyclecounter() : 0;
+    if (PROF && blk == 0) prof[6] = (t_stage - t_entry) & 0xffffffffu;  // low half: before the first page-table entry is asked for
     __syncthreads();  // every wave is done with the previous block's offsets and tiles
     for (int i = tid; i < n_blk; i += 64 * WAVES) {
       uint32_t s = (uint32_t)table_row[blk + i];
@@ -237,6 +239,7 @@ void prefill_mfma_kernel(PrefillArgs a) {
       }
     };
 
+    if (PROF) prof[5] += (__builtin_readcyclecounter() - t_stage) << 32;  // high half: staging the block's entries
     issue_step(0);
     if (n_steps > 1) issue_step(1);
 
@@ -419,6 +422,8 @@ hipError_t launch_tag(const PrefillArgs& a, hipStream_t stream) {
   int rt = g == 1 ? 1 : 2;
   const char* e = getenv("BSGL_PREFILL_RT");  // tuning override
   if (e != nullptr && *e != '\0') rt = atoi(e);
+  const char* e16 = getenv("BSGL_PREFILL_16");  // tuning override: keep this kernel where the 32x32x16 form applies
+  if (rt == 2 && prefill_mfma32_supported(a) && !(e16 != nullptr && *e16 == '1')) return launch_prefill_mfma32(a, stream);
   switch (rt) {
     case 1: return launch_rt<Tag, 1>(a, stream);
     case 2: return launch_rt<Tag, 2>(a, stream);

@@ -1,0 +1,424 @@
+// Matrix-core paged extend (prefill) attention for gfx950 on the 32x32x16 product shape
+// (bf16 / f16, head_dim 128, at least two q heads per kv head, 64-position blocks).
+//
+// Same contract, work list, K/V streaming and LDS image as paged_prefill_mfma.hip (reference:
+// _prefill_attention, attn_backend.py:34-110); what differs is how a workgroup's 64 positions x
+// 2 q heads are dealt to its four waves and which product shape they use.  A 16x16x32 product
+// holds the SIMD's vector issue for 8 of its 16 cycles, a 32x32x16 product for 8 of its 32 at
+// twice the arithmetic: with the softmax's exponentials, multiply-adds and conversions in the
+// gaps, the smaller shape is bound by instruction issue, the larger one by the matrix pipe.
+//
+// A wave owns 32 consecutive positions of ONE q head (wave & 1: which half of the block,
+// wave >> 1: which head).  Per step of 32 tokens:
+//   S^T[token][position] = K . Q^T      8 products (k = 16 each over head_dim 128); a lane then
+//                                       holds 16 of the 32 scores of ITS position (lane & 31),
+//                                       the partner lane (lane ^ 32) the other 16
+//   softmax in registers                row maximum = 15 maxima + one half-wave exchange
+//   O[position][d] += P . V             8 products: the score accumulator, rounded to the dtype,
+//                                       IS the A operand (position on the lane, tokens in the
+//                                       registers -- the order of summation over tokens is free
+//                                       as long as the V fragment uses the same one)
+// The steps are software-pipelined inside the wave as in the 16-row kernel: iteration i turns
+// scores i into probabilities while the matrix cores compute scores i + 1, then runs PV i.
+#include "bsgl_device.h"
+#include "bsgl_launch.h"
+#include "bsgl_mfma.h"
+
+#include <type_traits>
+
+namespace bsgl {
+
+namespace {
+
+using namespace mfma;
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <typename Tag> struct Mma32;
+template <> struct Mma32<bf16_tag> {
+  __device__ static __forceinline__ f32x16 mm(const uint4& a, const uint4& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma32<f16_tag> {
+  __device__ static __forceinline__ f32x16 mm(const uint4& a, const uint4& b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+};
+
+// row of the 32x32 accumulator that register r of a lane in half `hi` holds
+__device__ __forceinline__ constexpr int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+template <typename Tag>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+void prefill_mfma32_kernel(PrefillArgs a) {
+  using E = Elem<Tag>;
+  constexpr int D = 128;
+  constexpr int REC = 512;  // K row | V row of one kv head
+  constexpr int WAVES = 4;
+  constexpr int HPW = 2;    // q heads per workgroup
+  constexpr int ROWS = 64;  // positions per workgroup
+  constexpr int NSTAGE = 4;
+  constexpr int TILE_BYTES = kTile * REC;
+  constexpr int STEP = 2 * kTile;                  // tokens per step: two tiles
+  constexpr int STEP_BYTES = 2 * TILE_BYTES;
+  constexpr int DMA_PER_STEP = STEP_BYTES / 1024;  // 16 instructions, two tokens each
+  constexpr int DPW = DMA_PER_STEP / WAVES;        // instructions per wave and step
+  constexpr int RING = NSTAGE * STEP_BYTES;
+  constexpr int kOPad = D + 4;
+  constexpr int STAGE_OUT = 32 * kOPad * 4;        // output staging of one wave
+  constexpr int BUF = RING > WAVES * STAGE_OUT ? RING : WAVES * STAGE_OUT;
+  constexpr int SLOTS = kSlotBlock;
+  static_assert(SLOTS % STEP == 0, "");
+
+  __shared__ __attribute__((aligned(1024))) char smem[BUF + SLOTS * 4];
+  int32_t* s_slots = (int32_t*)(smem + BUF);
+  const uint32_t lds_ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+  const int tid = threadIdx.x;
+  const bool PROF = a.prof != nullptr;
+  const uint64_t t_entry = PROF ? __builtin_readcyclecounter() : 0;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lp = lane & 31;  // position inside the wave's 32 (column of S^T, row of O)
+  const int hi = lane >> 5;
+  const int G = a.n_q_heads / a.n_kv_heads;
+  const int fold = a.fold_group;  // folded heads: see paged_prefill_mfma.hip
+
+  // ---- which (request, block of 64 positions, kv head, pair of q heads) is this? ------------
+  // (the launch order of paged_prefill_mfma.hip: index = 8 * slot + xcd)
+  const int n_z = (G + HPW - 1) / HPW;
+  const int per_group = a.grp_blocks * n_z;
+  const unsigned slot = blockIdx.x >> 3;
+  const int64_t g = (int64_t)(slot / (unsigned)per_group) * 8 + (blockIdx.x & 7);
+  if (g >= a.cu_blk[a.batch] * a.n_kv_heads) return;
+  const int within = (int)(slot % (unsigned)per_group);
+  const int kvh = (int)(g % a.n_kv_heads);
+  const int64_t pg = g / a.n_kv_heads;
+  const int rt0 = (within % n_z) * HPW;
+  const int n_rt = min(HPW, G - rt0);
+  int i_req = 0;
+  for (int base = 1; base <= a.batch; base += 64) {
+    const int j = base + lane;
+    const bool le = j <= a.batch && a.cu_blk[j] <= pg;
+    i_req += __popcll(__ballot(le));
+  }
+  i_req = min(i_req, a.batch - 1);
+  const int64_t ext_raw = a.extended_lens[i_req];
+  const int n_blocks = (int)(((ext_raw < 0 ? 0 : ext_raw) + ROWS - 1) / ROWS);
+  const int bg0 = (int)(pg - a.cu_blk[i_req]) * a.grp_blocks;
+  const int nb = min(a.grp_blocks, n_blocks - bg0);
+  if (within / n_z >= nb) return;
+  const int q0_wg = (bg0 + nb - 1 - within / n_z) * ROWS;  // a request's last blocks first
+  const int rows_wg = (int)min((int64_t)ROWS, ext_raw - q0_wg);
+  const int hw = wave >> 1;                        // which of the workgroup's q heads
+  const int q0 = q0_wg + 32 * (wave & 1);
+  const bool head_ok = hw < n_rt;                  // a head past the group: the wave only helps to load
+  const int n_rows = head_ok ? max(0, min(32, rows_wg - 32 * (wave & 1))) : 0;
+  const int64_t q_row0 = a.cu_ext[i_req] + q0;
+  int64_t req = a.req_idx[i_req];
+  req = req < 0 ? 0 : (req >= a.kv.table_rows ? a.kv.table_rows - 1 : req);
+  const int64_t seq64 = a.seq_lens[i_req];
+  const int seq = (int)(seq64 < 0 ? 0 : (seq64 > a.kv.table_cols ? a.kv.table_cols : seq64));
+  const int64_t pre64 = a.prefix_lens[i_req];
+  const int prefix = (int)(pre64 < 0 ? 0 : (pre64 > seq ? seq : pre64));
+  const int kv_len = min(seq, prefix + q0_wg + rows_wg);
+  const int wave_len = n_rows > 0 ? min(kv_len, prefix + q0 + n_rows) : 0;
+  const int my_last = min(prefix + q0 + min(lp, max(n_rows, 1) - 1), kv_len - 1);
+  const int full_until = min(prefix + q0, kv_len - 1);
+  const int32_t* table_row = a.kv.table + req * a.kv.table_row_stride;
+  const uint32_t max_slot = (uint32_t)(a.kv.n_slots - 1);
+  const uint32_t row_units = (uint32_t)(a.kv.slab_row_stride * 2 / 16);
+  const int head = kvh * G + rt0 + hw;  // (folded: kvh = 0 and G counts the heads of both halves)
+
+  // ---- Q^T fragments: lane (position lp, half hi) holds Q[q_row0 + lp][head][16 kb + 8 hi ..] ----
+  uint4 qf[8];
+  {
+    const char* qrow = (const char*)a.q + (q_row0 + lp) * a.q_row_stride * 2;
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+      qf[kb] = make_uint4(0, 0, 0, 0);
+      if (lp < n_rows) {
+        if (fold == 0) {
+          qf[kb] = *(const uint4*)(qrow + ((int64_t)head * D + 16 * kb + 8 * hi) * 2);
+        } else if ((16 * kb + 8 * hi) / 64 == head / fold) {
+          qf[kb] = *(const uint4*)(qrow + ((int64_t)head * 64 + (16 * kb + 8 * hi) % 64) * 2);
+        }
+      }
+    }
+  }
+  const float scale_log2e = a.scale * kLog2e;
+
+  // ---- DMA source pieces: two tokens per instruction, [K 256 B | V 256 B] per token -----
+  const int piece = lane & 31;
+  const bool piece_is_v = piece >= 16;
+  const int lane_tok = lane >> 5;
+  const uint64_t lane_src = (uint64_t)(piece_is_v ? a.kv.v_slab : a.kv.k_slab) + (uint64_t)kvh * (D * 2) +
+                            (uint64_t)((((piece & 15)) ^ (lane_tok << 2)) << 4);
+
+  // K as the A operand: lane (token lp of the step, half hi) reads K[token][16 kb + 8 hi ..]
+  const int k_rec = rec_of_token(lp & 15);
+  int k_off[8];
+#pragma unroll
+  for (int kb = 0; kb < 8; ++kb)
+    k_off[kb] = (lp >> 4) * TILE_BYTES + k_rec * REC + (((2 * kb + hi) ^ xr_of_rec(k_rec)) << 4);
+  // V as the B operand through transposing reads: a 16-lane group fetches 4 tokens x 16 values
+  // (lane i of it: token i >> 2, values 4 (i & 3) ..) and lane i receives value column i of the
+  // four tokens.  The group's tokens: 8 jh + 4 hi + 0..3 of the tile, its columns
+  // 32 db + 16 (group & 1) ..
+  int v_off[2][4];
+  {
+    const int i16 = lane & 15, dh = (lane >> 4) & 1;
+#pragma unroll
+    for (int jh = 0; jh < 2; ++jh) {
+      const int rec = rec_of_token(8 * jh + 4 * hi + (i16 >> 2));
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+        v_off[jh][db] = rec * REC + 256 + (((4 * db + 2 * dh + ((i16 & 3) >> 1)) ^ xr_of_rec(rec)) << 4) + ((i16 & 1) << 3);
+    }
+  }
+
+  uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float m_run = kNegInf, neg_mc = 0.f;  // reference score of the lane's position, and -(that) * scale * log2(e)
+  constexpr float kSlack = 6.f;
+  const float slack_raw = kSlack / scale_log2e;
+  float l_run = 0.f;  // sum of this lane's probabilities (its 16 tokens of every step)
+  f32x16 o_acc[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[db][r] = 0.f;
+
+  for (int blk = 0; blk < kv_len; blk += SLOTS) {
+    const int n_blk = min(SLOTS, kv_len - blk);
+    const int n_steps = (n_blk + STEP - 1) / STEP;
+    const uint64_t t_stage = PROF ? __builtin_readcyclecounter() : 0;
+    if (PROF && blk == 0) prof[6] = (t_stage - t_entry) & 0xffffffffu;
+    __syncthreads();  // every wave is done with the previous block's offsets and tiles
+    for (int i = tid; i < n_blk; i += 64 * WAVES) {
+      uint32_t s = (uint32_t)table_row[blk + i];
+      s = s > max_slot ? max_slot : s;
+      s_slots[i] = (int32_t)(s * row_units);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // retire every compiler-visible load before the step loop
+    __syncthreads();
+
+    auto issue_step = [&](int step) {
+      const uint32_t stage = lds_ring + (uint32_t)(step % NSTAGE) * STEP_BYTES;
+      uint32_t off[DPW];
+#pragma unroll
+      for (int j = 0; j < DPW; ++j)
+        off[j] = (uint32_t)s_slots[min(step * STEP + 2 * (wave * DPW + j) + lane_tok, n_blk - 1)];
+#pragma unroll
+      for (int j = 0; j < DPW; ++j) {
+        const int i = wave * DPW + j;  // wave-uniform
+        const int t0 = 2 * (i & 7);
+        const uint32_t rec = (uint32_t)rec_of_token(t0);
+        const uint32_t xr = (uint32_t)xr_of_rec((int)rec);
+        uint64_t src = ((uint64_t)off[j] << 4) + lane_src;
+        src ^= (uint64_t)(xr << 4);
+        dma_1k<false>((const void*)src,
+                      __builtin_amdgcn_readfirstlane(stage + (uint32_t)(i >> 3) * TILE_BYTES + rec * REC));
+      }
+    };
+
+    if (PROF) prof[5] += (__builtin_readcyclecounter() - t_stage) << 32;
+    issue_step(0);
+    if (n_steps > 1) issue_step(1);
+    if (n_steps > 2) issue_step(2);
+
+    // raw scores of the step about to be consumed and of the one after it: the two trade places
+    // from step to step (a copy would wait for the last score product)
+    f32x16 sc_a, sc_b;
+    auto load_k = [&](uint4 (&kf)[8], const char* st) {
+#pragma unroll
+      for (int kb = 0; kb < 8; ++kb) kf[kb] = *(const uint4*)(st + k_off[kb]);
+    };
+    auto scores = [&](const uint4 (&kf)[8]) {
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 8; ++kb) s = Mma32<Tag>::mm(kf[kb], qf[kb], s);
+      return s;
+    };
+    {
+      if (n_steps > 2) dma_wait<2 * DPW>(); else if (n_steps > 1) dma_wait<DPW>(); else dma_wait<0>();
+      __syncthreads();
+      if (blk < wave_len) {
+        uint4 kf[8];
+        load_k(kf, smem);
+        sc_a = scores(kf);
+      }
+    }
+
+    auto do_step = [&](int step, auto stage_c, f32x16& sc, f32x16& sn) {
+      constexpr int STAGE = decltype(stage_c)::value;
+      constexpr int NEXT = (STAGE + 1) % NSTAGE;
+      const uint64_t t0 = PROF ? __builtin_readcyclecounter() : 0;
+      const bool has_next = step + 1 < n_steps;  // wave-uniform
+      uint64_t t1 = t0, t2 = t0;
+      if (has_next) {
+        // this wave's share of step + 1 has landed (one younger step may stay in flight) ...
+        if (step + 2 < n_steps) dma_wait<DPW>(); else dma_wait<0>();
+        t1 = PROF ? __builtin_readcyclecounter() : 0;
+        // ... and so has everybody's; all waves are also done reading step - 1
+        __syncthreads();
+        t2 = PROF ? __builtin_readcyclecounter() : 0;
+        if (step + 3 < n_steps) issue_step(step + 3);  // into the stage step - 1 used
+      }
+      const uint64_t t3 = PROF ? __builtin_readcyclecounter() : 0;
+      if (PROF) { prof[0] += t1 - t0; prof[1] += t2 - t1; prof[2] += t3 - t2; prof[5] += 1; }
+      const char* st = smem + STAGE * STEP_BYTES;
+      if (blk + step * STEP >= wave_len) return;  // nothing this wave's rows may see (wave-uniform)
+
+      // K fragments of step + 1 (whatever the stage holds if there is no such step: the scores
+      // made of them are then never used); they travel while the maximum is looked at
+      uint4 kf[8];
+      load_k(kf, smem + NEXT * STEP_BYTES);
+
+      const bool step_masked = blk + step * STEP + STEP - 1 > full_until;  // wave-uniform
+      if (step_masked) {
+        int t0m = blk + step * STEP + 4 * hi;
+        asm volatile("" : "+v"(t0m));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = (t0m + acc_row(r, 0) <= my_last) ? sc[r] : kNegInf;
+      }
+      // lazy running maximum: see paged_prefill_mfma.hip
+      float lmax = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
+      lmax = fmaxf(lmax, fmaxf(fmaxf(fmaxf(sc[8], sc[9]), fmaxf(sc[10], sc[11])), fmaxf(fmaxf(sc[12], sc[13]), fmaxf(sc[14], sc[15]))));
+      if (__any(lmax > m_run + slack_raw)) {
+        float x = lmax, y = lmax;
+        swap32(x, y);  // the partner lane holds the position's other 16 tokens
+        const float m_new = fmaxf(m_run, fmaxf(x, y));
+        // a position with nothing visible yet keeps m = -inf: its factor is 1, not exp2(nan)
+        const float alpha = m_new == kNegInf ? 1.f : fast_exp2((m_run - m_new) * scale_log2e);
+        m_run = m_new;
+        neg_mc = -(m_new == kNegInf ? 0.f : m_new) * scale_log2e;  // masked scores: exp2(-inf) = 0
+        l_run *= alpha;
+        // O has its positions in the registers: register r of this lane belongs to position
+        // acc_row(r, hi), whose factor lives on lane acc_row(r, hi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float ar = __shfl(alpha, acc_row(r, 0) + 4 * hi);
+#pragma unroll
+          for (int db = 0; db < 4; ++db) o_acc[db][r] *= ar;
+        }
+      }
+
+      // ---- from here to the end of the step: one basic block, issued in the order written ----
+      // (a scheduling barrier after every product: the compiler's own order puts the vector
+      // work in clumps and waits for every LDS read right behind its issue).  A product holds
+      // the vector issue for 8 of its 32 cycles; the gap takes one or two exponentials (8
+      // cycles each) and a few 4-cycle instructions.
+      auto v_frag = [&](int i) {  // V fragment of PV product i: tile i >> 2, value columns 32 (i & 3) ..
+        const s16x4_t va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t*)(st + (i >> 2) * TILE_BYTES + v_off[0][i & 3]));
+        const s16x4_t vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4_t*)(st + (i >> 2) * TILE_BYTES + v_off[1][i & 3]));
+        const uint2 va2 = __builtin_bit_cast(uint2, va), vb2 = __builtin_bit_cast(uint2, vb);
+        return make_uint4(va2.x, va2.y, vb2.x, vb2.y);
+      };
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sn[r] = 0.f;
+      float e[16], p[16];
+      uint32_t pw[8];  // probabilities, two to a word: words 4 kk .. 4 kk + 3 = the A operand of tile kk
+      uint4 vf[3];
+      e[0] = fmaf(sc[0], scale_log2e, neg_mc);
+      e[1] = fmaf(sc[1], scale_log2e, neg_mc);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kb = 0; kb < 8; ++kb) {
+        sn = Mma32<Tag>::mm(kf[kb], qf[kb], sn);
+        p[2 * kb] = fast_exp2(e[2 * kb]);
+        p[2 * kb + 1] = fast_exp2(e[2 * kb + 1]);
+        if (kb < 7) {
+          e[2 * kb + 2] = fmaf(sc[2 * kb + 2], scale_log2e, neg_mc);
+          e[2 * kb + 3] = fmaf(sc[2 * kb + 3], scale_log2e, neg_mc);
+        }
+        if (kb >= 4) pw[kb - 4] = E::pack2(p[2 * (kb - 4)], p[2 * (kb - 4) + 1]);
+        if (kb >= 6) vf[kb - 6] = v_frag(kb - 6);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // k-values of a lane in PV product i: registers 8 kk .. 8 kk + 7 of the score accumulator,
+      // i.e. tokens {0-3, 8-11} + 4 hi of tile kk = i >> 2
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int kk = i >> 2;
+        o_acc[i & 3] = Mma32<Tag>::mm(make_uint4(pw[4 * kk], pw[4 * kk + 1], pw[4 * kk + 2], pw[4 * kk + 3]), vf[i % 3], o_acc[i & 3]);
+        if (i + 2 < 8) vf[(i + 2) % 3] = v_frag(i + 2);
+        if (i < 4) pw[4 + i] = E::pack2(p[8 + 2 * i], p[8 + 2 * i + 1]);
+        // (as instructions of their own, here: the compiler otherwise pairs the sums into packed adds
+        // and parks them at the head of the next step)
+        asm volatile("v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2" : "+v"(l_run) : "v"(p[2 * i]), "v"(p[2 * i + 1]));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (PROF) prof[3] += __builtin_readcyclecounter() - t3;
+    };
+    static_assert(NSTAGE == 4, "the step loop below is unrolled over the ring");
+    for (int step = 0; step < n_steps; step += 4) {
+      do_step(step, std::integral_constant<int, 0>{}, sc_a, sc_b);
+      if (step + 1 < n_steps) do_step(step + 1, std::integral_constant<int, 1>{}, sc_b, sc_a);
+      if (step + 2 < n_steps) do_step(step + 2, std::integral_constant<int, 2>{}, sc_a, sc_b);
+      if (step + 3 < n_steps) do_step(step + 3, std::integral_constant<int, 3>{}, sc_b, sc_a);
+    }
+  }
+
+  const uint64_t t_loop_end = PROF ? __builtin_readcyclecounter() : 0;
+  // ---- normalise and write: rows through LDS so that a lane stores 16 contiguous bytes ----
+  __syncthreads();  // the ring is free: each wave stages its rows in its own region
+  float* o_lds = (float*)(smem + wave * STAGE_OUT);
+  {
+    float x = l_run, y = l_run;
+    swap32(x, y);
+    const float l_pos = x + y;  // both halves of the position's tokens
+    const float inv = l_pos > 0.f ? 1.f / l_pos : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float ir = __shfl(inv, acc_row(r, 0) + 4 * hi);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) o_lds[(acc_row(r, 0) + 4 * hi) * kOPad + 32 * db + lp] = o_acc[db][r] * ir;
+    }
+    for (int idx = lane; idx < n_rows * (D / 8); idx += 64) {
+      const int r = idx / (D / 8), c8 = idx % (D / 8);
+      const float* src = o_lds + r * kOPad + c8 * 8;
+      const uint4 packed = make_uint4(E::pack2(src[0], src[1]), E::pack2(src[2], src[3]),
+                                      E::pack2(src[4], src[5]), E::pack2(src[6], src[7]));
+      if (fold == 0) {
+        *(uint4*)((char*)a.out + ((q_row0 + r) * a.out_row_stride + (int64_t)head * D + c8 * 8) * 2) = packed;
+      } else if ((c8 * 8) / 64 == head / fold) {
+        *(uint4*)((char*)a.out + ((q_row0 + r) * a.out_row_stride + (int64_t)head * 64 + (c8 * 8) % 64) * 2) = packed;
+      }
+    }
+  }
+  if (PROF && lane == 0) {
+    prof[7] = __builtin_readcyclecounter() - t_entry;
+    prof[6] |= (uint64_t)(prof[7] - (t_loop_end - t_entry)) << 32;
+    uint64_t* dst = a.prof + 8 * ((uint64_t)blockIdx.x * WAVES + wave);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[i] = prof[i];
+  }
+}
+
+}  // namespace
+
+bool prefill_mfma32_supported(const PrefillArgs& a) {
+  return a.blk_rows == 64 && a.n_kv_heads > 0 && a.n_q_heads / a.n_kv_heads >= 2;
+}
+
+// the grid of paged_prefill_mfma.hip's launch with two q heads per workgroup
+hipError_t launch_prefill_mfma32(const PrefillArgs& a, hipStream_t stream) {
+  const int group = a.n_q_heads / a.n_kv_heads;
+  const int n_z = (group + 1) / 2;
+  const int64_t local_groups = ((int64_t)a.max_groups * a.n_kv_heads + 7) / 8;
+  const int64_t n_wg = 8 * local_groups * a.grp_blocks * n_z;
+  if (n_wg > 0x7fffffffll) return hipErrorInvalidValue;
+  dim3 grid((unsigned)n_wg, 1, 1);
+  if (a.dtype == kBF16)
+    hipLaunchKernelGGL((prefill_mfma32_kernel<bf16_tag>), grid, dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL((prefill_mfma32_kernel<f16_tag>), grid, dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace bsgl

@@ -82,6 +82,8 @@ def main():
         ti = buf.cpu()
         ti = ti[ti[:, 7] > 0]
         t = ti.double()
+        staging = (ti[:, 5] >> 32).double()
+        t[:, 5] = (ti[:, 5] & 0xFFFFFFFF).double()
         steps = t[:, 5].sum()
         names = ("own-DMA wait", "barrier", "DMA issue", "score+softmax", "PV")
         tot = t[:, :5].sum()
@@ -92,9 +94,9 @@ def main():
         pro = ti[:, 6] & 0xFFFFFFFF
         epi = ti[:, 6] >> 32
         life = t[:, 7]
-        print(f"  per wave: whole life {life.mean():.0f} cycles = before the first K/V request {pro.double().mean():.0f} "
-              f"+ steps {t[:, :5].sum(1).mean():.0f} + after the last step {epi.double().mean():.0f} "
-              f"+ rest {life.mean() - pro.double().mean() - t[:, :5].sum(1).mean() - epi.double().mean():.0f}")
+        print(f"  per wave: whole life {life.mean():.0f} cycles = before the first page-table read {pro.double().mean():.0f} "
+              f"+ staging the entries {staging.mean():.0f} + steps {t[:, :5].sum(1).mean():.0f} + after the last step {epi.double().mean():.0f} "
+              f"+ rest {life.mean() - pro.double().mean() - staging.mean() - t[:, :5].sum(1).mean() - epi.double().mean():.0f}")
 
 
 if __name__ == "__main__":
