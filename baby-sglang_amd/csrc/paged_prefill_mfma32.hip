@@ -69,9 +69,9 @@ void prefill_mfma32_kernel(PrefillArgs a) {
   constexpr int STAGE_OUT = 32 * kOPad * 4;        // output staging of one wave
   constexpr int BUF = RING > WAVES * STAGE_OUT ? RING : WAVES * STAGE_OUT;
   constexpr int SLOTS = kSlotBlock;
-  static_assert(SLOTS % STEP == 0, "");
+  static_assert(SLOTS == 2 * 64 * WAVES && SLOTS / STEP == 16, "two entries per thread and block; steps per block as shifted below");
 
-  __shared__ __attribute__((aligned(1024))) char smem[BUF + SLOTS * 4];
+  __shared__ __attribute__((aligned(1024))) char smem[BUF + 2 * SLOTS * 4];
   int32_t* s_slots = (int32_t*)(smem + BUF);
   const uint32_t lds_ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
@@ -189,83 +189,116 @@ void prefill_mfma32_kernel(PrefillArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o_acc[db][r] = 0.f;
 
-  for (int blk = 0; blk < kv_len; blk += SLOTS) {
-    const int n_blk = min(SLOTS, kv_len - blk);
-    const int n_steps = (n_blk + STEP - 1) / STEP;
-    const uint64_t t_stage = PROF ? __builtin_readcyclecounter() : 0;
-    if (PROF && blk == 0) prof[6] = (t_stage - t_entry) & 0xffffffffu;
-    __syncthreads();  // every wave is done with the previous block's offsets and tiles
-    for (int i = tid; i < n_blk; i += 64 * WAVES) {
-      uint32_t s = (uint32_t)table_row[blk + i];
-      s = s > max_slot ? max_slot : s;
-      s_slots[i] = (int32_t)(s * row_units);
+  // The page-table entries of the sequence are staged SLOTS at a time into the two halves of
+  // s_slots; block b + 1 is fetched while block b is being worked on, so the K/V stream never
+  // drains between blocks.  Each thread fetches two entries of a block.
+  const int n_steps = (kv_len + STEP - 1) / STEP;
+  auto entry_ptr = [&](int e) { return table_row + max(min(e, kv_len - 1), 0); };  // entries past the end repeat the last one
+  auto entry_off = [&](uint32_t s) { return (int32_t)((s > max_slot ? max_slot : s) * row_units); };
+  const uint64_t t_stage = PROF ? __builtin_readcyclecounter() : 0;
+  if (PROF) prof[6] = (t_stage - t_entry) & 0xffffffffu;
+  {
+    const uint32_t e0 = (uint32_t)*entry_ptr(tid), e1 = (uint32_t)*entry_ptr(tid + 256);
+    s_slots[tid] = entry_off(e0);
+    s_slots[tid + 256] = entry_off(e1);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // retire every compiler-visible load before the step loop
+  __syncthreads();
+  uint32_t ent0 = 0, ent1 = 0;  // entries of the next block on their way (asm loads, awaited by the step waits)
+
+  // a step is loaded by all waves together: wave w issues instructions w*DPW .. w*DPW+DPW-1;
+  // instruction i brings tokens 2i, 2i+1 of the step (tile i / 8)
+  // (the row offsets of a step are read from s_slots one request early, so that the request
+  // itself does not start with an LDS round trip)
+  uint32_t off[DPW];
+  auto read_offsets = [&](int step) {
+    const int32_t* ent = s_slots + ((step * STEP) & (2 * SLOTS - 1)) + 2 * wave * DPW + lane_tok;
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) off[j] = (uint32_t)ent[2 * j];
+  };
+  auto issue_step = [&](int step) {
+    const uint32_t stage = lds_ring + (uint32_t)(step % NSTAGE) * STEP_BYTES;
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) {
+      const int i = wave * DPW + j;  // wave-uniform
+      const int t0 = 2 * (i & 7);
+      const uint32_t rec = (uint32_t)rec_of_token(t0);
+      const uint32_t xr = (uint32_t)xr_of_rec((int)rec);
+      uint64_t src = ((uint64_t)off[j] << 4) + lane_src;
+      src ^= (uint64_t)(xr << 4);
+      dma_1k<false>((const void*)src,
+                    __builtin_amdgcn_readfirstlane(stage + (uint32_t)(i >> 3) * TILE_BYTES + rec * REC));
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // retire every compiler-visible load before the step loop
+  };
+
+  if (PROF) prof[5] += (__builtin_readcyclecounter() - t_stage) << 32;
+  if (n_steps > 0) { read_offsets(0); issue_step(0); }
+  if (n_steps > 1) { read_offsets(1); issue_step(1); }
+  if (n_steps > 2) { read_offsets(2); issue_step(2); }
+  if (n_steps > 3) read_offsets(3);
+
+  // raw scores of the step about to be consumed and of the one after it: the two trade places
+  // from step to step (a copy would wait for the last score product)
+  f32x16 sc_a, sc_b;
+  auto load_k = [&](uint4 (&kf)[8], const char* st) {
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) kf[kb] = *(const uint4*)(st + k_off[kb]);
+  };
+  auto scores = [&](const uint4 (&kf)[8]) {
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) s = Mma32<Tag>::mm(kf[kb], qf[kb], s);
+    return s;
+  };
+  {
+    if (n_steps > 2) dma_wait<2 * DPW>(); else if (n_steps > 1) dma_wait<DPW>(); else dma_wait<0>();
     __syncthreads();
-
-    auto issue_step = [&](int step) {
-      const uint32_t stage = lds_ring + (uint32_t)(step % NSTAGE) * STEP_BYTES;
-      uint32_t off[DPW];
-#pragma unroll
-      for (int j = 0; j < DPW; ++j)
-        off[j] = (uint32_t)s_slots[min(step * STEP + 2 * (wave * DPW + j) + lane_tok, n_blk - 1)];
-#pragma unroll
-      for (int j = 0; j < DPW; ++j) {
-        const int i = wave * DPW + j;  // wave-uniform
-        const int t0 = 2 * (i & 7);
-        const uint32_t rec = (uint32_t)rec_of_token(t0);
-        const uint32_t xr = (uint32_t)xr_of_rec((int)rec);
-        uint64_t src = ((uint64_t)off[j] << 4) + lane_src;
-        src ^= (uint64_t)(xr << 4);
-        dma_1k<false>((const void*)src,
-                      __builtin_amdgcn_readfirstlane(stage + (uint32_t)(i >> 3) * TILE_BYTES + rec * REC));
-      }
-    };
-
-    if (PROF) prof[5] += (__builtin_readcyclecounter() - t_stage) << 32;
-    issue_step(0);
-    if (n_steps > 1) issue_step(1);
-    if (n_steps > 2) issue_step(2);
-
-    // raw scores of the step about to be consumed and of the one after it: the two trade places
-    // from step to step (a copy would wait for the last score product)
-    f32x16 sc_a, sc_b;
-    auto load_k = [&](uint4 (&kf)[8], const char* st) {
-#pragma unroll
-      for (int kb = 0; kb < 8; ++kb) kf[kb] = *(const uint4*)(st + k_off[kb]);
-    };
-    auto scores = [&](const uint4 (&kf)[8]) {
-      f32x16 s;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 8; ++kb) s = Mma32<Tag>::mm(kf[kb], qf[kb], s);
-      return s;
-    };
-    {
-      if (n_steps > 2) dma_wait<2 * DPW>(); else if (n_steps > 1) dma_wait<DPW>(); else dma_wait<0>();
-      __syncthreads();
-      if (blk < wave_len) {
-        uint4 kf[8];
-        load_k(kf, smem);
-        sc_a = scores(kf);
-      }
+    if (0 < wave_len) {
+      uint4 kf[8];
+      load_k(kf, smem);
+      sc_a = scores(kf);
     }
+  }
 
+  {
+    constexpr int blk = 0;
     auto do_step = [&](int step, auto stage_c, f32x16& sc, f32x16& sn) {
       constexpr int STAGE = decltype(stage_c)::value;
       constexpr int NEXT = (STAGE + 1) % NSTAGE;
       const uint64_t t0 = PROF ? __builtin_readcyclecounter() : 0;
       const bool has_next = step + 1 < n_steps;  // wave-uniform
       uint64_t t1 = t0, t2 = t0;
+      // the entries of block b + 1 are asked for in step 16 b + 2 (behind that step's K/V
+      // requests), have arrived by the wait of step 16 b + 4 and are stored then; their half of
+      // s_slots was last read for step 16 b - 1, requested in step 16 b - 4, and is first read
+      // for step 16 b + 16, requested in step 16 b + 13
+      const int in_blk = step & (SLOTS / STEP - 1);
+      const bool more_entries = ((step >> 4) + 1) * SLOTS < kv_len;  // wave-uniform
       if (has_next) {
-        // this wave's share of step + 1 has landed (one younger step may stay in flight) ...
-        if (step + 2 < n_steps) dma_wait<DPW>(); else dma_wait<0>();
+        // this wave's share of step + 1 has landed (one younger step may stay in flight, and in
+        // step 16 b + 3 the two entry loads behind it) ...
+        if (step + 2 >= n_steps) dma_wait<0>();
+        else if (in_blk == 3 && more_entries) dma_wait<DPW + 2>();
+        else dma_wait<DPW>();
         t1 = PROF ? __builtin_readcyclecounter() : 0;
+        if (in_blk == 4 && more_entries) {
+          asm volatile("" : "+v"(ent0), "+v"(ent1));  // (not to be read before the wait above)
+          int32_t* half = s_slots + (((step >> 4) + 1) & 1) * SLOTS;
+          half[tid] = entry_off(ent0);
+          half[tid + 256] = entry_off(ent1);
+        }
         // ... and so has everybody's; all waves are also done reading step - 1
         __syncthreads();
         t2 = PROF ? __builtin_readcyclecounter() : 0;
         if (step + 3 < n_steps) issue_step(step + 3);  // into the stage step - 1 used
+        if (step + 4 < n_steps) read_offsets(step + 4);
+        if (in_blk == 2 && more_entries) {
+          const int e = ((step >> 4) + 1) * SLOTS + tid;
+          asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off"
+                       : "=&v"(ent0), "=&v"(ent1) : "v"(entry_ptr(e)), "v"(entry_ptr(e + 256)) : "memory");
+        }
       }
       const uint64_t t3 = PROF ? __builtin_readcyclecounter() : 0;
       if (PROF) { prof[0] += t1 - t0; prof[1] += t2 - t1; prof[2] += t3 - t2; prof[5] += 1; }
@@ -323,7 +356,7 @@ void prefill_mfma32_kernel(PrefillArgs a) {
       for (int r = 0; r < 16; ++r) sn[r] = 0.f;
       float e[16], p[16];
       uint32_t pw[8];  // probabilities, two to a word: words 4 kk .. 4 kk + 3 = the A operand of tile kk
-      uint4 vf[3];
+      uint4 vf[4];  // V fragments travel three products ahead of their use
       e[0] = fmaf(sc[0], scale_log2e, neg_mc);
       e[1] = fmaf(sc[1], scale_log2e, neg_mc);
       __builtin_amdgcn_sched_barrier(0);
@@ -337,7 +370,7 @@ void prefill_mfma32_kernel(PrefillArgs a) {
           e[2 * kb + 3] = fmaf(sc[2 * kb + 3], scale_log2e, neg_mc);
         }
         if (kb >= 4) pw[kb - 4] = E::pack2(p[2 * (kb - 4)], p[2 * (kb - 4) + 1]);
-        if (kb >= 6) vf[kb - 6] = v_frag(kb - 6);
+        if (kb >= 5) vf[kb - 5] = v_frag(kb - 5);
         __builtin_amdgcn_sched_barrier(0);
       }
       // k-values of a lane in PV product i: registers 8 kk .. 8 kk + 7 of the score accumulator,
@@ -345,8 +378,8 @@ void prefill_mfma32_kernel(PrefillArgs a) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int kk = i >> 2;
-        o_acc[i & 3] = Mma32<Tag>::mm(make_uint4(pw[4 * kk], pw[4 * kk + 1], pw[4 * kk + 2], pw[4 * kk + 3]), vf[i % 3], o_acc[i & 3]);
-        if (i + 2 < 8) vf[(i + 2) % 3] = v_frag(i + 2);
+        o_acc[i & 3] = Mma32<Tag>::mm(make_uint4(pw[4 * kk], pw[4 * kk + 1], pw[4 * kk + 2], pw[4 * kk + 3]), vf[i % 4], o_acc[i & 3]);
+        if (i + 3 < 8) vf[(i + 3) % 4] = v_frag(i + 3);
         if (i < 4) pw[4 + i] = E::pack2(p[8 + 2 * i], p[8 + 2 * i + 1]);
         // (as instructions of their own, here: the compiler otherwise pairs the sums into packed adds
         // and parks them at the head of the next step)
@@ -414,8 +447,10 @@ hipError_t launch_prefill_mfma32(const PrefillArgs& a, hipStream_t stream) {
   const int64_t n_wg = 8 * local_groups * a.grp_blocks * n_z;
   if (n_wg > 0x7fffffffll) return hipErrorInvalidValue;
   dim3 grid((unsigned)n_wg, 1, 1);
+  const char* pad_e = getenv("BSGL_PREFILL_LDS_PAD");
+  const unsigned pad = pad_e != nullptr ? (unsigned)atoi(pad_e) : 0u;
   if (a.dtype == kBF16)
-    hipLaunchKernelGGL((prefill_mfma32_kernel<bf16_tag>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((prefill_mfma32_kernel<bf16_tag>), grid, dim3(256), pad, stream, a);
   else
     hipLaunchKernelGGL((prefill_mfma32_kernel<f16_tag>), grid, dim3(256), 0, stream, a);
   return hipGetLastError();
