@@ -512,6 +512,33 @@ def test_prefill_kernels_agree(gpu, dtype, hq, hkv):
         assert_close(got_mfma, want, dtype, "matrix-core extend")
 
 
+@pytest.mark.parametrize("dtype,hq,hkv,dim", [(torch.bfloat16, 28, 4, 128), (torch.float16, 12, 2, 128), (torch.float16, 6, 2, 128),
+                                              (torch.bfloat16, 14, 2, 64)])
+def test_extend_over_many_page_table_blocks(gpu, dtype, hq, hkv, dim):
+    """Sequences of several page-table blocks (512 entries each) in one stream: a chunk deep
+    inside a long request, a long pure prefill whose causal edge crosses block borders, lengths
+    one short of / at / one past a block border, and an odd number of q heads per kv head (the
+    last pair of heads of a group is half empty)."""
+    from baby_sglang_amd import _hip
+
+    seq_lens = [2600, 1500, 1024, 1025, 1023, 90]
+    prefix_lens = [2100, 0, 960, 1000, 1000, 26]
+    cpu, r2t, kv = random_decode_problem(gpu, dtype, hq, hkv, dim, seq_lens, seed=hq + dim)
+    ext = [s - p for s, p in zip(seq_lens, prefix_lens)]
+    gen = torch.Generator().manual_seed(4)
+    q = torch.randn((sum(ext), hq, dim), generator=gen).to(dtype)
+    pl, el = torch.tensor(prefix_lens), torch.tensor(ext)
+    want = orc.prefill_exact(q, cpu["k_slab"], cpu["v_slab"], cpu["req_to_token"], cpu["req_pool_indices"], cpu["seq_lens"], pl, el)
+    spread = orc.prefill_exact(q, cpu["k_slab"], cpu["v_slab"].abs(), cpu["req_to_token"], cpu["req_pool_indices"], cpu["seq_lens"], pl, el)
+    k_slab, v_slab = kv.get_kv_buffer(0)
+    got = _hip.paged_prefill(q.to(gpu), k_slab, v_slab, r2t.req_to_token, cpu["req_pool_indices"].to(gpu),
+                             cpu["seq_lens"].to(gpu), pl.to(gpu), el.to(gpu), variant=2)
+    ulp = 2.0**-8 if dtype == torch.bfloat16 else 2.0**-11
+    err = (got.double().cpu() - want).abs()
+    bound = ulp * want.abs() + ulp * spread + 2e-4
+    assert bool(torch.isfinite(got).all()) and bool((err <= bound).all()), f"worst excess {(err - bound).max().item():.3e}"
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("slope", [0.02, 0.4])
 def test_extend_scores_rising_along_the_sequence(gpu, dtype, slope):

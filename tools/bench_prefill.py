@@ -85,12 +85,12 @@ def main():
         staging = (ti[:, 5] >> 32).double()
         t[:, 5] = (ti[:, 5] & 0xFFFFFFFF).double()
         steps = t[:, 5].sum()
-        names = ("own-DMA wait", "barrier", "DMA issue", "score+softmax", "PV")
+        names = ("own-DMA wait", "barrier", "DMA issue", "score+softmax (32x32x16 kernel: whole step body)", "PV (16x16x32 kernel only)")
         tot = t[:, :5].sum()
         print(f"  {len(t)} waves, {int(steps)} wave-steps; cycles per wave-step by phase:")
         for i, n in enumerate(names):
-            print(f"    {n:14s} {t[:, i].sum() / steps:8.0f}  ({t[:, i].sum() / tot:6.1%})")
-        print(f"    {'sum':14s} {tot / steps:8.0f}")
+            print(f"    {n:50s} {t[:, i].sum() / steps:8.0f}  ({t[:, i].sum() / tot:6.1%})")
+        print(f"    {'sum':50s} {tot / steps:8.0f}")
         pro = ti[:, 6] & 0xFFFFFFFF
         epi = ti[:, 6] >> 32
         life = t[:, 7]
