@@ -142,7 +142,10 @@ int run_decode(bsgl::DecodeArgs& a, int32_t variant, uint32_t* counters, hipStre
   // (folded heads: the workgroup that merges a request reads the partial rows of ALL its q heads,
   // 14 for Qwen2.5-0.5B: more than 8 pieces per request cost more in that merge than they gain)
   // -- and with half as many kv heads to cut, up to n_splits pieces are wanted below that
-  if (a.fold_group > 0 && a.balance_target > 0) a.balance_target = a.n_splits < 8 ? a.n_splits : 8;
+  if (a.fold_group > 0 && a.balance_target > 0) {
+    const int cap = env_int("BSGL_FOLD_PIECES", 8);
+    a.balance_target = a.n_splits < cap ? a.n_splits : cap;
+  }
   const hipError_t e = use_mfma ? bsgl::launch_decode_mfma(a, stream) : bsgl::launch_decode_valu(a, stream);
   if (e != hipSuccess) return hip_fail("decode launch", e);
   return BSGL_OK;

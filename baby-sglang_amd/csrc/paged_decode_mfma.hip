@@ -55,6 +55,8 @@
 #include "bsgl_launch.h"
 #include "bsgl_mfma.h"
 
+#include <type_traits>
+
 namespace bsgl {
 
 namespace {
@@ -427,11 +429,14 @@ void decode_mfma_kernel(DecodeArgs a) {
       if (fused_merge) __hip_atomic_store(pl, lse, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else *pl = lse;
     }
+    // (folded heads: only the 64 values of the head's own kv head are kept, head h at floats
+    // [64 h, 64 h + 64) of the request's block, so that two heads make one 128-wide row for the merge)
     for (int idx = lane; idx < G * (D / 4); idx += 64) {
       const int q = idx / (D / 4), c4 = idx % (D / 4);
+      if (fold != 0 && c4 / (D / 8) != q / fold) continue;
       const f32x4 v = *(const f32x4*)(o_lds + q * kOPad + c4 * 4);
       // aux 16 = sc1: write-through, so the merging workgroup's sc1 loads see the bytes
-      const int off = ((hq0 + q) * D + c4 * 4) * 4;
+      const int off = fold == 0 ? ((hq0 + q) * D + c4 * 4) * 4 : ((hq0 + q) * (D / 2) + (c4 % (D / 8)) * 4) * 4;
       if (fused_merge) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ws_rsrc, off, 0, 16);
       else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), ws_rsrc, off, 0, 0);
     }
@@ -461,68 +466,88 @@ void decode_mfma_kernel(DecodeArgs a) {
   const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ws_o + rh0 * D), 0, (int)((((int64_t)(n_parts - 1) * n_rh + nh) * D) * 4), 0x00020000);
   const int part_lse_stride = (int)(n_rh * 4);
   const int part_o_stride = (int)(n_rh * D * 4);
-  constexpr int kMH = 6;  // heads per round (the GQA group of the 1.5B model in one round)
-  constexpr int kMP = 8;  // parts per round; kMH * kMP * 2 registers hold a round's partial rows
-  for (int h0 = 0; h0 < nh; h0 += kMH) {
-    float my_lse[kMH];
-    // (unconditional loads, clamped to a real part: they all leave together)
+  // A "row" of the merge is 128 floats of a part: one q head, or (folded heads) two q heads of 64
+  // values, the lower 32 lanes on the first of them.  PAIR = heads per row.
+  auto merge_rows = [&](auto pair_c) {
+    constexpr int PAIR = decltype(pair_c)::value;
+    constexpr int kMH = PAIR == 2 ? 7 : 6;  // rows per round (the GQA group of the 1.5B model, the 14 heads of the 0.5B model)
+    constexpr int kMP = 8;                  // parts per round; kMH * kMP * 2 registers hold a round's partial rows
+    const int n_mrows = nh / PAIR;
+    const int sub = PAIR == 2 ? lane >> 5 : 0;  // which head of the row this lane works on
+    for (int h0 = 0; h0 < n_mrows; h0 += kMH) {
+      float my_lse[kMH][PAIR];
+      // (unconditional loads, clamped to a real part: they all leave together)
 #pragma unroll
-    for (int j = 0; j < kMH; ++j) {
-      const int h = min(h0 + j, nh - 1);
-      my_lse[j] = as_f32(__builtin_amdgcn_raw_buffer_load_b32(lse_rsrc, min(lane, n_parts - 1) * part_lse_stride + h * 4, 0, 16));
-    }
-    float acc[kMH][2];
-    float my_w[kMH], mx[kMH], wsum[kMH];
+      for (int j = 0; j < kMH; ++j)
 #pragma unroll
-    for (int j = 0; j < kMH; ++j) acc[j][0] = acc[j][1] = 0.f;
-    for (int p0 = 0; p0 < n_parts; p0 += kMP) {
-      u32x2_t v[kMH][kMP];
-#pragma unroll
-      for (int j = 0; j < kMH; ++j) {
-        const int h = min(h0 + j, nh - 1);
-#pragma unroll
-        for (int i = 0; i < kMP; ++i) {
-          const int p = min(p0 + i, n_parts - 1);
-          v[j][i] = __builtin_amdgcn_raw_buffer_load_b64(o_rsrc, p * part_o_stride + (h * D + lane * 2) * 4, 0, 16);
+        for (int s = 0; s < PAIR; ++s) {
+          const int h = min(h0 + j, n_mrows - 1) * PAIR + s;
+          my_lse[j][s] = as_f32(__builtin_amdgcn_raw_buffer_load_b32(lse_rsrc, min(lane, n_parts - 1) * part_lse_stride + h * 4, 0, 16));
         }
-      }
-      if (p0 == 0) {  // (first use of the lse loads: after the partial rows have been requested)
+      float acc[kMH][2];
+      float my_w[kMH][PAIR], mx[kMH][PAIR], wsum[kMH][PAIR];
+#pragma unroll
+      for (int j = 0; j < kMH; ++j) acc[j][0] = acc[j][1] = 0.f;
+      for (int p0 = 0; p0 < n_parts; p0 += kMP) {
+        u32x2_t v[kMH][kMP];
 #pragma unroll
         for (int j = 0; j < kMH; ++j) {
-          my_lse[j] = lane < n_parts ? my_lse[j] : kNegInf;
-          mx[j] = group_max<64>(my_lse[j]);
-          my_w[j] = (my_lse[j] == kNegInf) ? 0.f : fast_exp2((my_lse[j] - mx[j]) * kLog2e);
-          wsum[j] = group_sum<64>(my_w[j]);
+          const int h = min(h0 + j, n_mrows - 1);
+#pragma unroll
+          for (int i = 0; i < kMP; ++i) {
+            const int p = min(p0 + i, n_parts - 1);
+            v[j][i] = __builtin_amdgcn_raw_buffer_load_b64(o_rsrc, p * part_o_stride + (h * D + lane * 2) * 4, 0, 16);
+          }
+        }
+        if (p0 == 0) {  // (first use of the lse loads: after the partial rows have been requested)
+#pragma unroll
+          for (int j = 0; j < kMH; ++j)
+#pragma unroll
+            for (int s = 0; s < PAIR; ++s) {
+              my_lse[j][s] = lane < n_parts ? my_lse[j][s] : kNegInf;
+              mx[j][s] = group_max<64>(my_lse[j][s]);
+              my_w[j][s] = (my_lse[j][s] == kNegInf) ? 0.f : fast_exp2((my_lse[j][s] - mx[j][s]) * kLog2e);
+              wsum[j][s] = group_sum<64>(my_w[j][s]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < kMH; ++j) {
+#pragma unroll
+          for (int i = 0; i < kMP; ++i) {
+            const int p = min(p0 + i, n_parts - 1);
+            float w = __shfl(my_w[j][0], p);
+            if (PAIR == 2) {
+              const float w1 = __shfl(my_w[j][1], p);
+              w = sub ? w1 : w;
+            }
+            w = p0 + i < n_parts ? w : 0.f;
+            acc[j][0] = fmaf(w, as_f32(v[j][i].x), acc[j][0]);
+            acc[j][1] = fmaf(w, as_f32(v[j][i].y), acc[j][1]);
+          }
         }
       }
 #pragma unroll
       for (int j = 0; j < kMH; ++j) {
-#pragma unroll
-        for (int i = 0; i < kMP; ++i) {
-          const float w = p0 + i < n_parts ? __shfl(my_w[j], min(p0 + i, n_parts - 1)) : 0.f;
-          acc[j][0] = fmaf(w, as_f32(v[j][i].x), acc[j][0]);
-          acc[j][1] = fmaf(w, as_f32(v[j][i].y), acc[j][1]);
+        if (h0 + j >= n_mrows) break;
+        const float ws = PAIR == 2 && sub ? wsum[j][PAIR - 1] : wsum[j][0];
+        const float inv = ws > 0.f ? 1.f / ws : 0.f;
+        const int64_t hq = (int64_t)head0 * G + (int64_t)(h0 + j) * PAIR + sub;
+        // (PAIR == 2: head hq's 64 values are columns [64 hq, 64 hq + 64) of the output row as well)
+        const int64_t col = PAIR == 2 ? hq * 64 + (lane * 2) % 64 : hq * D + lane * 2;
+        if (a.out_dtype == kF32) {
+          *(float2*)((char*)a.out + ((int64_t)row * a.out_row_stride + col) * 4) = make_float2(acc[j][0] * inv, acc[j][1] * inv);
+        } else {
+          *(uint32_t*)((char*)a.out + ((int64_t)row * a.out_row_stride + col) * 2) = E::pack2(acc[j][0] * inv, acc[j][1] * inv);
+        }
+        if (a.lse != nullptr && (lane & 31) == 0 && (PAIR == 2 || lane == 0)) {
+          const float m = PAIR == 2 && sub ? mx[j][PAIR - 1] : mx[j][0];
+          a.lse[rh0 + (h0 + j) * PAIR + sub] = ws > 0.f ? m + __builtin_amdgcn_logf(ws) * kLn2 : kNegInf;
         }
       }
     }
-#pragma unroll
-    for (int j = 0; j < kMH; ++j) {
-      if (h0 + j >= nh) break;
-      const float inv = wsum[j] > 0.f ? 1.f / wsum[j] : 0.f;
-      const int64_t hq = (int64_t)head0 * G + h0 + j;
-      // (folded heads: lanes holding the other kv head's half of the row do not store)
-      const bool keep = fold == 0 || (lane * 2) / 64 == (int)hq / fold;
-      const int64_t col = fold == 0 ? hq * D + lane * 2 : hq * 64 + (lane * 2) % 64;
-      if (!keep) {
-      } else if (a.out_dtype == kF32) {
-        *(float2*)((char*)a.out + ((int64_t)row * a.out_row_stride + col) * 4) = make_float2(acc[j][0] * inv, acc[j][1] * inv);
-      } else {
-        *(uint32_t*)((char*)a.out + ((int64_t)row * a.out_row_stride + col) * 2) = E::pack2(acc[j][0] * inv, acc[j][1] * inv);
-      }
-      if (a.lse != nullptr && lane == 0)
-        a.lse[rh0 + h0 + j] = wsum[j] > 0.f ? mx[j] + __builtin_amdgcn_logf(wsum[j]) * kLn2 : kNegInf;
-    }
-  }
+  };
+  if (fold != 0) merge_rows(std::integral_constant<int, 2>{});
+  else merge_rows(std::integral_constant<int, 1>{});
   if (lane == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (trace != nullptr && lane == 0) trace[3] = wall_clock64() | (1ull << 63);  // top bit: this one merged
 }
