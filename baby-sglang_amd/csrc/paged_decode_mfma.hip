@@ -468,12 +468,18 @@ void decode_mfma_kernel(DecodeArgs a) {
   const int part_o_stride = (int)(n_rh * D * 4);
   // A "row" of the merge is 128 floats of a part: one q head, or (folded heads) two q heads of 64
   // values, the lower 32 lanes on the first of them.  PAIR = heads per row.
+  // Partial rows come in 16 bytes per lane: the lower half of the wave reads the even parts of a
+  // round, the upper half the odd ones (a load instruction costs the wave some 80 cycles to issue
+  // whatever its width, so the merge is paid in instructions), and the two halves' sums are
+  // added at the end.
   auto merge_rows = [&](auto pair_c) {
     constexpr int PAIR = decltype(pair_c)::value;
     constexpr int kMH = PAIR == 2 ? 7 : 6;  // rows per round (the GQA group of the 1.5B model, the 14 heads of the 0.5B model)
     constexpr int kMP = 8;                  // parts per round; kMH * kMP * 2 registers hold a round's partial rows
     const int n_mrows = nh / PAIR;
-    const int sub = PAIR == 2 ? lane >> 5 : 0;  // which head of the row this lane works on
+    const int hp = lane >> 5;               // parity of the parts this lane reads
+    const int c4 = lane & 31;               // its four floats of a row: c4 * 4 ..
+    const int sub = PAIR == 2 ? c4 >> 4 : 0;  // which head of the row they belong to
     for (int h0 = 0; h0 < n_mrows; h0 += kMH) {
       float my_lse[kMH][PAIR];
       // (unconditional loads, clamped to a real part: they all leave together)
@@ -484,19 +490,19 @@ void decode_mfma_kernel(DecodeArgs a) {
           const int h = min(h0 + j, n_mrows - 1) * PAIR + s;
           my_lse[j][s] = as_f32(__builtin_amdgcn_raw_buffer_load_b32(lse_rsrc, min(lane, n_parts - 1) * part_lse_stride + h * 4, 0, 16));
         }
-      float acc[kMH][2];
+      f32x4 acc[kMH];
       float my_w[kMH][PAIR], mx[kMH][PAIR], wsum[kMH][PAIR];
 #pragma unroll
-      for (int j = 0; j < kMH; ++j) acc[j][0] = acc[j][1] = 0.f;
+      for (int j = 0; j < kMH; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
       for (int p0 = 0; p0 < n_parts; p0 += kMP) {
-        u32x2_t v[kMH][kMP];
+        u32x4_t v[kMH][kMP / 2];
 #pragma unroll
         for (int j = 0; j < kMH; ++j) {
           const int h = min(h0 + j, n_mrows - 1);
 #pragma unroll
-          for (int i = 0; i < kMP; ++i) {
-            const int p = min(p0 + i, n_parts - 1);
-            v[j][i] = __builtin_amdgcn_raw_buffer_load_b64(o_rsrc, p * part_o_stride + (h * D + lane * 2) * 4, 0, 16);
+          for (int i = 0; i < kMP / 2; ++i) {
+            const int p = min(p0 + 2 * i + hp, n_parts - 1);
+            v[j][i] = __builtin_amdgcn_raw_buffer_load_b128(o_rsrc, p * part_o_stride + (h * D + c4 * 4) * 4, 0, 16);
           }
         }
         if (p0 == 0) {  // (first use of the lse loads: after the partial rows have been requested)
@@ -513,35 +519,46 @@ void decode_mfma_kernel(DecodeArgs a) {
 #pragma unroll
         for (int j = 0; j < kMH; ++j) {
 #pragma unroll
-          for (int i = 0; i < kMP; ++i) {
-            const int p = min(p0 + i, n_parts - 1);
+          for (int i = 0; i < kMP / 2; ++i) {
+            const int p = min(p0 + 2 * i + hp, n_parts - 1);
             float w = __shfl(my_w[j][0], p);
             if (PAIR == 2) {
               const float w1 = __shfl(my_w[j][1], p);
               w = sub ? w1 : w;
             }
-            w = p0 + i < n_parts ? w : 0.f;
-            acc[j][0] = fmaf(w, as_f32(v[j][i].x), acc[j][0]);
-            acc[j][1] = fmaf(w, as_f32(v[j][i].y), acc[j][1]);
+            w = p0 + 2 * i + hp < n_parts ? w : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(w, as_f32(v[j][i][e]), acc[j][e]);
           }
         }
       }
 #pragma unroll
       for (int j = 0; j < kMH; ++j) {
         if (h0 + j >= n_mrows) break;
+        float r4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {  // even parts + odd parts
+          float x = acc[j][e], y = acc[j][e];
+          swap32(x, y);
+          r4[e] = x + y;
+        }
         const float ws = PAIR == 2 && sub ? wsum[j][PAIR - 1] : wsum[j][0];
         const float inv = ws > 0.f ? 1.f / ws : 0.f;
         const int64_t hq = (int64_t)head0 * G + (int64_t)(h0 + j) * PAIR + sub;
         // (PAIR == 2: head hq's 64 values are columns [64 hq, 64 hq + 64) of the output row as well)
-        const int64_t col = PAIR == 2 ? hq * 64 + (lane * 2) % 64 : hq * D + lane * 2;
-        if (a.out_dtype == kF32) {
-          *(float2*)((char*)a.out + ((int64_t)row * a.out_row_stride + col) * 4) = make_float2(acc[j][0] * inv, acc[j][1] * inv);
-        } else {
-          *(uint32_t*)((char*)a.out + ((int64_t)row * a.out_row_stride + col) * 2) = E::pack2(acc[j][0] * inv, acc[j][1] * inv);
-        }
-        if (a.lse != nullptr && (lane & 31) == 0 && (PAIR == 2 || lane == 0)) {
-          const float m = PAIR == 2 && sub ? mx[j][PAIR - 1] : mx[j][0];
-          a.lse[rh0 + (h0 + j) * PAIR + sub] = ws > 0.f ? m + __builtin_amdgcn_logf(ws) * kLn2 : kNegInf;
+        const int64_t col = PAIR == 2 ? hq * 64 + (c4 * 4) % 64 : hq * D + c4 * 4;
+        if (hp == 0) {
+          if (a.out_dtype == kF32) {
+            *(float4*)((char*)a.out + ((int64_t)row * a.out_row_stride + col) * 4) =
+                make_float4(r4[0] * inv, r4[1] * inv, r4[2] * inv, r4[3] * inv);
+          } else {
+            *(uint2*)((char*)a.out + ((int64_t)row * a.out_row_stride + col) * 2) =
+                make_uint2(E::pack2(r4[0] * inv, r4[1] * inv), E::pack2(r4[2] * inv, r4[3] * inv));
+          }
+          if (a.lse != nullptr && (c4 & 15) == 0 && (PAIR == 2 || c4 == 0)) {
+            const float m = PAIR == 2 && sub ? mx[j][PAIR - 1] : mx[j][0];
+            a.lse[rh0 + (h0 + j) * PAIR + sub] = ws > 0.f ? m + __builtin_amdgcn_logf(ws) * kLn2 : kNegInf;
+          }
         }
       }
     }

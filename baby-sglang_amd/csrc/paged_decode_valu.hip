@@ -239,9 +239,11 @@ __global__ __launch_bounds__(256) void merge_states_kernel(MergeArgs a) {
   const float mx = group_max<64>(my_lse);
   const float my_w = (my_lse == kNegInf) ? 0.f : fast_exp2((my_lse - mx) * kLog2e);
   const float wsum = group_sum<64>(my_w);
-  float acc[EPL];
+  // (even and odd parts are summed apart and added at the end: the order of the decode kernel's
+  // own merge, whose wave halves read the parts of either parity, so that the two agree bit for bit)
+  float acc2[2][EPL];
 #pragma unroll
-  for (int i = 0; i < EPL; ++i) acc[i] = 0.f;
+  for (int i = 0; i < EPL; ++i) acc2[0][i] = acc2[1][i] = 0.f;
   const float* po = a.parts_o + rh * D + lane * EPL;
   const int64_t part_stride = n_rh * D;
   for (int p0 = 0; p0 < a.n_parts; p0 += 8) {
@@ -258,10 +260,13 @@ __global__ __launch_bounds__(256) void merge_states_kernel(MergeArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      acc[0] = fmaf(w[j], v[j].x, acc[0]);
-      if constexpr (EPL == 2) acc[1] = fmaf(w[j], v[j].y, acc[1]);
+      acc2[j & 1][0] = fmaf(w[j], v[j].x, acc2[j & 1][0]);
+      if constexpr (EPL == 2) acc2[j & 1][1] = fmaf(w[j], v[j].y, acc2[j & 1][1]);
     }
   }
+  float acc[EPL];
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) acc[i] = acc2[0][i] + acc2[1][i];
   const float inv = wsum > 0.f ? 1.f / wsum : 0.f;
   const int64_t row = rh / a.n_heads;
   const int head = (int)(rh % a.n_heads);

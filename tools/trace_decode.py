@@ -18,9 +18,11 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--kv-layout", default="interleaved")
+    ap.add_argument("--shape", default="12,2,128", help="q heads, kv heads, head_dim")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
-    B, S, hq, hkv, dim, layers = args.batch, args.seq, 12, 2, 128, 4
+    hq, hkv, dim = (int(x) for x in args.shape.split(","))
+    B, S, layers = args.batch, args.seq, 4
     g = torch.Generator().manual_seed(0)
     if args.lens == "ragged":
         lens = torch.randint(S // 2, 3 * S // 2, (B,), generator=g, dtype=torch.int64)
@@ -48,7 +50,7 @@ def main():
 
     def call(layer):
         k, v = kv.get_kv_buffer(layer)
-        _hip.paged_decode(q[layer], k, v, table, req, seq, n_splits=args.splits, variant=2, out=out, workspace=ws,
+        _hip.paged_decode(q[layer], k, v, table, req, seq, n_splits=args.splits, variant=0 if dim != 128 else 2, out=out, workspace=ws,
                           uniform_splits=args.uniform)
 
     for layer in range(layers):
