@@ -472,8 +472,13 @@ void decode_mfma_kernel(DecodeArgs a) {
   // round, the upper half the odd ones (a load instruction costs the wave some 80 cycles to issue
   // whatever its width, so the merge is paid in instructions), and the two halves' sums are
   // added at the end.
-  auto merge_rows = [&](auto pair_c) {
+  // The weights: lane (head k of a load, part p) = P2 * k + p holds lse and weight of its (head,
+  // part), P2 = 8 lanes per head for up to 8 parts (64 otherwise), so one
+  // load instruction fetches 64 / P2 heads' values and the maxima and sums run inside P2 lanes.
+  auto merge_rows = [&](auto pair_c, auto p2_c) {
     constexpr int PAIR = decltype(pair_c)::value;
+    constexpr int P2 = decltype(p2_c)::value;
+    constexpr int HPI = 64 / P2;  // heads per lse load
     constexpr int kMH = PAIR == 2 ? 7 : 6;  // rows per round (the GQA group of the 1.5B model, the 14 heads of the 0.5B model)
     constexpr int kMP = 8;                  // parts per round; kMH * kMP * 2 registers hold a round's partial rows
     const int n_mrows = nh / PAIR;
@@ -481,17 +486,15 @@ void decode_mfma_kernel(DecodeArgs a) {
     const int c4 = lane & 31;               // its four floats of a row: c4 * 4 ..
     const int sub = PAIR == 2 ? c4 >> 4 : 0;  // which head of the row they belong to
     for (int h0 = 0; h0 < n_mrows; h0 += kMH) {
-      float my_lse[kMH][PAIR];
-      // (unconditional loads, clamped to a real part: they all leave together)
+      constexpr int NL = (kMH * PAIR + HPI - 1) / HPI;  // lse loads of a round
+      float my_lse[NL], my_w[NL], mx[NL], wsum[NL];
+      // (unconditional loads, clamped to a real head and part: they all leave together)
 #pragma unroll
-      for (int j = 0; j < kMH; ++j)
-#pragma unroll
-        for (int s = 0; s < PAIR; ++s) {
-          const int h = min(h0 + j, n_mrows - 1) * PAIR + s;
-          my_lse[j][s] = as_f32(__builtin_amdgcn_raw_buffer_load_b32(lse_rsrc, min(lane, n_parts - 1) * part_lse_stride + h * 4, 0, 16));
-        }
+      for (int k = 0; k < NL; ++k) {
+        const int h = min(h0 * PAIR + k * HPI + lane / P2, nh - 1);
+        my_lse[k] = as_f32(__builtin_amdgcn_raw_buffer_load_b32(lse_rsrc, min(lane % P2, n_parts - 1) * part_lse_stride + h * 4, 0, 16));
+      }
       f32x4 acc[kMH];
-      float my_w[kMH][PAIR], mx[kMH][PAIR], wsum[kMH][PAIR];
 #pragma unroll
       for (int j = 0; j < kMH; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
       for (int p0 = 0; p0 < n_parts; p0 += kMP) {
@@ -507,23 +510,21 @@ void decode_mfma_kernel(DecodeArgs a) {
         }
         if (p0 == 0) {  // (first use of the lse loads: after the partial rows have been requested)
 #pragma unroll
-          for (int j = 0; j < kMH; ++j)
-#pragma unroll
-            for (int s = 0; s < PAIR; ++s) {
-              my_lse[j][s] = lane < n_parts ? my_lse[j][s] : kNegInf;
-              mx[j][s] = group_max<64>(my_lse[j][s]);
-              my_w[j][s] = (my_lse[j][s] == kNegInf) ? 0.f : fast_exp2((my_lse[j][s] - mx[j][s]) * kLog2e);
-              wsum[j][s] = group_sum<64>(my_w[j][s]);
-            }
+          for (int k = 0; k < NL; ++k) {
+            my_lse[k] = lane % P2 < n_parts ? my_lse[k] : kNegInf;
+            mx[k] = group_max<P2>(my_lse[k]);
+            my_w[k] = (my_lse[k] == kNegInf) ? 0.f : fast_exp2((my_lse[k] - mx[k]) * kLog2e);
+            wsum[k] = group_sum<P2>(my_w[k]);
+          }
         }
 #pragma unroll
         for (int j = 0; j < kMH; ++j) {
 #pragma unroll
           for (int i = 0; i < kMP / 2; ++i) {
             const int p = min(p0 + 2 * i + hp, n_parts - 1);
-            float w = __shfl(my_w[j][0], p);
+            float w = __shfl(my_w[(j * PAIR) / HPI], ((j * PAIR) % HPI) * P2 + p);
             if (PAIR == 2) {
-              const float w1 = __shfl(my_w[j][1], p);
+              const float w1 = __shfl(my_w[(j * PAIR + 1) / HPI], ((j * PAIR + 1) % HPI) * P2 + p);
               w = sub ? w1 : w;
             }
             w = p0 + 2 * i + hp < n_parts ? w : 0.f;
@@ -542,7 +543,14 @@ void decode_mfma_kernel(DecodeArgs a) {
           swap32(x, y);
           r4[e] = x + y;
         }
-        const float ws = PAIR == 2 && sub ? wsum[j][PAIR - 1] : wsum[j][0];
+        float ws = __shfl(wsum[(j * PAIR) / HPI], ((j * PAIR) % HPI) * P2);
+        float m = __shfl(mx[(j * PAIR) / HPI], ((j * PAIR) % HPI) * P2);
+        if (PAIR == 2) {
+          const float ws1 = __shfl(wsum[(j * PAIR + 1) / HPI], ((j * PAIR + 1) % HPI) * P2);
+          const float m1 = __shfl(mx[(j * PAIR + 1) / HPI], ((j * PAIR + 1) % HPI) * P2);
+          ws = sub ? ws1 : ws;
+          m = sub ? m1 : m;
+        }
         const float inv = ws > 0.f ? 1.f / ws : 0.f;
         const int64_t hq = (int64_t)head0 * G + (int64_t)(h0 + j) * PAIR + sub;
         // (PAIR == 2: head hq's 64 values are columns [64 hq, 64 hq + 64) of the output row as well)
@@ -556,15 +564,19 @@ void decode_mfma_kernel(DecodeArgs a) {
                 make_uint2(E::pack2(r4[0] * inv, r4[1] * inv), E::pack2(r4[2] * inv, r4[3] * inv));
           }
           if (a.lse != nullptr && (c4 & 15) == 0 && (PAIR == 2 || c4 == 0)) {
-            const float m = PAIR == 2 && sub ? mx[j][PAIR - 1] : mx[j][0];
             a.lse[rh0 + (h0 + j) * PAIR + sub] = ws > 0.f ? m + __builtin_amdgcn_logf(ws) * kLn2 : kNegInf;
           }
         }
       }
     }
   };
-  if (fold != 0) merge_rows(std::integral_constant<int, 2>{});
-  else merge_rows(std::integral_constant<int, 1>{});
+  auto merge_p2 = [&](auto pair_c) {
+    // (16 lanes per head for 9 - 16 parts was measured too: slower than one head per load)
+    if (n_parts <= 8) merge_rows(pair_c, std::integral_constant<int, 8>{});
+    else merge_rows(pair_c, std::integral_constant<int, 64>{});
+  };
+  if (fold != 0) merge_p2(std::integral_constant<int, 2>{});
+  else merge_p2(std::integral_constant<int, 1>{});
   if (lane == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (trace != nullptr && lane == 0) trace[3] = wall_clock64() | (1ull << 63);  // top bit: this one merged
 }
