@@ -282,11 +282,27 @@ void decode_mfma_kernel(DecodeArgs a) {
   for (int blk = start; blk < end; blk += kSlotBlock) {
     const int n_blk = min(kSlotBlock, end - blk);
     const int n_tiles = (n_blk + kTile - 1) / kTile;
-    for (int i = lane; i < n_blk; i += 64) {
-      uint32_t s = (uint32_t)table_row[blk + i];
-      s = s > max_slot ? max_slot : s;
-      // row offset of the slot in 16-byte units (host checked that it stays below 2^32 - 1)
-      s_slots[i] = (int32_t)(s == new_slot ? kNewTok : s * row_units);
+    // The block's page-table entries: all loads first (clamped to the block, so that nothing
+    // branches between them), then the LDS writes.  Written as a loop of load - write pairs the
+    // compiler waits for every load before it issues the next: up to 8 memory round trips at
+    // the head of every workgroup while HBM idles.
+    {
+      auto stage_entries = [&](auto n_c) {
+        constexpr int N = decltype(n_c)::value;
+        uint32_t ent[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) ent[j] = (uint32_t)table_row[blk + min(lane + 64 * j, n_blk - 1)];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          uint32_t s = ent[j] > max_slot ? max_slot : ent[j];
+          // row offset of the slot in 16-byte units (host checked that it stays below 2^32 - 1)
+          if (lane + 64 * j < n_blk) s_slots[lane + 64 * j] = (int32_t)(s == new_slot ? kNewTok : s * row_units);
+        }
+      };
+      static_assert(kSlotBlock == 512, "entries per lane below");
+      if (n_blk <= 128) stage_entries(std::integral_constant<int, 2>{});
+      else if (n_blk <= 256) stage_entries(std::integral_constant<int, 4>{});
+      else stage_entries(std::integral_constant<int, 8>{});
     }
     // (same wave: the LDS writes above are ordered before the LDS reads below)
     // Retire every load the compiler knows about (q fragments, page-table entries)
