@@ -139,6 +139,10 @@ int run_decode(bsgl::DecodeArgs& a, int32_t variant, uint32_t* counters, hipStre
   a.balance_target = 0;
   if (a.counters != nullptr && a.n_splits > 1 && a.rows <= 1024 && a.kv.table_cols <= (1 << 20) && !uniform_splits && env_int("BSGL_DECODE_BALANCE", 1) != 0)
     a.balance_target = (a.n_splits + 1) / 2;
+  if (a.balance_target > 0) {
+    const int t = env_int("BSGL_DECODE_TARGET", 0);  // tuning override: pieces wanted per request
+    if (t > 0 && t <= a.n_splits) a.balance_target = t;
+  }
   // (folded heads: the workgroup that merges a request reads the partial rows of ALL its q heads,
   // 14 for Qwen2.5-0.5B: more than 8 pieces per request cost more in that merge than they gain)
   // -- and with half as many kv heads to cut, up to n_splits pieces are wanted below that
