@@ -108,13 +108,22 @@ void prefill_mfma32_kernel(PrefillArgs a) {
   const int n_blocks = (int)(((ext_raw < 0 ? 0 : ext_raw) + ROWS - 1) / ROWS);
   const int bg0 = (int)(pg - a.cu_blk[i_req]) * a.grp_blocks;
   const int nb = min(a.grp_blocks, n_blocks - bg0);
-  if (within / n_z >= nb) return;
-  const int q0_wg = (bg0 + nb - 1 - within / n_z) * ROWS;  // a request's last blocks first
+  const int bi = within / n_z;  // block of the group, counted from the request's end (last blocks first)
+  if (bi >= nb) return;
+  // The last pair of an odd GQA group holds one q head.  Its workgroups then take TWO blocks of
+  // that head each (waves 2, 3 the block before the one of waves 0, 1; the stream is the longer
+  // one's) instead of leaving half their waves without work, and every second one of them retires.
+  const bool two_blocks = n_rt == 1;
+  if (two_blocks && (bi & 1)) return;
+  const int q0_wg = (bg0 + nb - 1 - bi) * ROWS;
   const int rows_wg = (int)min((int64_t)ROWS, ext_raw - q0_wg);
-  const int hw = wave >> 1;                        // which of the workgroup's q heads
-  const int q0 = q0_wg + 32 * (wave & 1);
-  const bool head_ok = hw < n_rt;                  // a head past the group: the wave only helps to load
-  const int n_rows = head_ok ? max(0, min(32, rows_wg - 32 * (wave & 1))) : 0;
+  const int hw = wave >> 1;                        // which of the workgroup's q heads (or blocks)
+  const int my_bi = bi + (two_blocks ? hw : 0);
+  const bool head_ok = two_blocks ? my_bi < nb : hw < n_rt;  // no such head / block: the wave only helps to load
+  const int q0_blk = (bg0 + nb - 1 - (head_ok ? my_bi : bi)) * ROWS;
+  const int rows_blk = (int)min((int64_t)ROWS, ext_raw - q0_blk);
+  const int q0 = q0_blk + 32 * (wave & 1);
+  const int n_rows = head_ok ? max(0, min(32, rows_blk - 32 * (wave & 1))) : 0;
   const int64_t q_row0 = a.cu_ext[i_req] + q0;
   int64_t req = a.req_idx[i_req];
   req = req < 0 ? 0 : (req >= a.kv.table_rows ? a.kv.table_rows - 1 : req);
@@ -129,7 +138,7 @@ void prefill_mfma32_kernel(PrefillArgs a) {
   const int32_t* table_row = a.kv.table + req * a.kv.table_row_stride;
   const uint32_t max_slot = (uint32_t)(a.kv.n_slots - 1);
   const uint32_t row_units = (uint32_t)(a.kv.slab_row_stride * 2 / 16);
-  const int head = kvh * G + rt0 + hw;  // (folded: kvh = 0 and G counts the heads of both halves)
+  const int head = kvh * G + rt0 + (two_blocks ? 0 : hw);  // (folded: kvh = 0 and G counts the heads of both halves)
 
   // ---- Q^T fragments: lane (position lp, half hi) holds Q[q_row0 + lp][head][16 kb + 8 hi ..] ----
   uint4 qf[8];
