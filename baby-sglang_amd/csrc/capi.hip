@@ -373,18 +373,36 @@ int bsgl_paged_prefill(void* out, int64_t out_row_stride, const void* q, int64_t
   pa.cu_blk = ex.cu_blk;
   pa.batch = batch;
   pa.total_q_tokens = total_q_tokens;
-  // 64 query positions per workgroup unless the extends are very short on average
-  pa.blk_rows = (int64_t)total_q_tokens >= 24ll * batch ? 64 : 16;
+  // 64 query positions per workgroup unless the extends are short on average.  With several q
+  // heads per kv head a 16-position workgroup serves 8 of them from one K/V stream (measured
+  // against 64 positions x 2 heads: faster up to 32 new tokens per request, equal at 48, slower
+  // from 64); with one q head per kv head it is the single-wave kernel, worth it below 24.
+  const int64_t short_below = n_kv_heads > 0 && n_q_heads / n_kv_heads >= 2 ? 44 : 24;
+  pa.blk_rows = (int64_t)total_q_tokens >= short_below * batch ? 64 : 16;
   {
     const int forced = env_int("BSGL_PREFILL_BLK", 0);  // tuning override
     if (forced == 16 || forced == 64) pa.blk_rows = forced;
   }
   ex.blk_rows = pa.blk_rows;
-  // groups of 8 consecutive blocks of a request share an XCD (and with it an L2)
-  pa.grp_blocks = env_int("BSGL_PREFILL_GROUP", 8) > 0 ? env_int("BSGL_PREFILL_GROUP", 8) : 8;
+  // Groups of up to 8 consecutive blocks of a request share an XCD (and with it an L2).  The grid
+  // holds a workgroup for every block slot of every group, and the slots a request does not fill
+  // retire at once -- but dispatching them is not free (batches of one-block requests in groups
+  // of 8 spent 4/5 of the launch on it), so the group is no larger than the mean request needs.
+  {
+    const int64_t per = (int64_t)pa.blk_rows * (batch > 0 ? batch : 1);
+    const int64_t mean_blocks = ((int64_t)total_q_tokens + per - 1) / per;
+    int grp = 1;
+    while (grp < 8 && grp < mean_blocks) grp *= 2;
+    const int forced = env_int("BSGL_PREFILL_GROUP", 0);  // tuning override
+    pa.grp_blocks = forced > 0 ? forced : grp;
+  }
   ex.grp_blocks = pa.grp_blocks;
-  // bound on the number of (request, block group) entries: sum ceil(blocks_i / g) <= blocks / g + batch
-  pa.max_groups = ((total_q_tokens + pa.blk_rows - 1) / pa.blk_rows + batch) / pa.grp_blocks + batch + 1;
+  // bound on the number of (request, block group) entries: blocks <= total / rows + batch, and
+  // sum ceil(blocks_i / g) <= blocks / g + batch (for g = 1 the groups are the blocks)
+  {
+    const int64_t blocks = ((int64_t)total_q_tokens + pa.blk_rows - 1) / pa.blk_rows + batch;
+    pa.max_groups = (int32_t)(pa.grp_blocks == 1 ? blocks : blocks / pa.grp_blocks + batch + 1);
+  }
   pa.prof = g_prefill_prof;
   pa.n_q_heads = n_q_heads;
   pa.n_kv_heads = n_kv_heads;

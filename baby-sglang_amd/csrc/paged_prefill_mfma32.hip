@@ -49,15 +49,20 @@ template <> struct Mma32<f16_tag> {
 // row of the 32x32 accumulator that register r of a lane in half `hi` holds
 __device__ __forceinline__ constexpr int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
-template <typename Tag>
+// PW = positions among a wave's 32 columns.  32: the layout above (64 positions x 2 q heads per
+// workgroup).  16: for batches of short extends a wave's columns are 2 q heads x 16 positions and
+// the workgroup covers 16 positions x 8 q heads, so a kv head's K/V is streamed by ONE workgroup
+// for up to 8 q heads instead of once per pair of heads.
+template <typename Tag, int PW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 void prefill_mfma32_kernel(PrefillArgs a) {
   using E = Elem<Tag>;
   constexpr int D = 128;
   constexpr int REC = 512;  // K row | V row of one kv head
   constexpr int WAVES = 4;
-  constexpr int HPW = 2;    // q heads per workgroup
-  constexpr int ROWS = 64;  // positions per workgroup
+  constexpr int CH = 32 / PW;                    // q heads among a wave's columns
+  constexpr int HPW = PW == 32 ? 2 : WAVES * CH;  // q heads per workgroup
+  constexpr int ROWS = PW == 32 ? 64 : PW;        // positions per workgroup
   constexpr int NSTAGE = 4;
   constexpr int TILE_BYTES = kTile * REC;
   constexpr int STEP = 2 * kTile;                  // tokens per step: two tiles
@@ -80,7 +85,9 @@ void prefill_mfma32_kernel(PrefillArgs a) {
   const uint64_t t_entry = PROF ? __builtin_readcyclecounter() : 0;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lp = lane & 31;  // position inside the wave's 32 (column of S^T, row of O)
+  const int lp = lane & 31;  // column of S^T, row of O
+  const int pos = lp % PW;   // its position inside the wave's PW ...
+  const int hsub = lp / PW;  // ... and its q head among the wave's CH
   const int hi = lane >> 5;
   const int G = a.n_q_heads / a.n_kv_heads;
   const int fold = a.fold_group;  // folded heads: see paged_prefill_mfma.hip
@@ -113,17 +120,20 @@ void prefill_mfma32_kernel(PrefillArgs a) {
   // The last pair of an odd GQA group holds one q head.  Its workgroups then take TWO blocks of
   // that head each (waves 2, 3 the block before the one of waves 0, 1; the stream is the longer
   // one's) instead of leaving half their waves without work, and every second one of them retires.
-  const bool two_blocks = n_rt == 1;
+  const bool two_blocks = PW == 32 && n_rt == 1;
   if (two_blocks && (bi & 1)) return;
   const int q0_wg = (bg0 + nb - 1 - bi) * ROWS;
   const int rows_wg = (int)min((int64_t)ROWS, ext_raw - q0_wg);
-  const int hw = wave >> 1;                        // which of the workgroup's q heads (or blocks)
+  const int hw = PW == 32 ? wave >> 1 : wave * CH;  // first of this wave's q heads among the workgroup's (or its block)
   const int my_bi = bi + (two_blocks ? hw : 0);
   const bool head_ok = two_blocks ? my_bi < nb : hw < n_rt;  // no such head / block: the wave only helps to load
   const int q0_blk = (bg0 + nb - 1 - (head_ok ? my_bi : bi)) * ROWS;
   const int rows_blk = (int)min((int64_t)ROWS, ext_raw - q0_blk);
-  const int q0 = q0_blk + 32 * (wave & 1);
-  const int n_rows = head_ok ? max(0, min(32, rows_blk - 32 * (wave & 1))) : 0;
+  const int pos_off = PW == 32 ? 32 * (wave & 1) : 0;
+  const int q0 = q0_blk + pos_off;
+  const int n_heads = PW == 32 ? (head_ok ? 1 : 0) : max(0, min(CH, n_rt - hw));  // q heads this wave really has
+  const int n_rows = n_heads > 0 ? max(0, min(PW, rows_blk - pos_off)) : 0;       // positions it really has
+  const bool col_ok = pos < n_rows && hsub < n_heads;
   const int64_t q_row0 = a.cu_ext[i_req] + q0;
   int64_t req = a.req_idx[i_req];
   req = req < 0 ? 0 : (req >= a.kv.table_rows ? a.kv.table_rows - 1 : req);
@@ -133,21 +143,22 @@ void prefill_mfma32_kernel(PrefillArgs a) {
   const int prefix = (int)(pre64 < 0 ? 0 : (pre64 > seq ? seq : pre64));
   const int kv_len = min(seq, prefix + q0_wg + rows_wg);
   const int wave_len = n_rows > 0 ? min(kv_len, prefix + q0 + n_rows) : 0;
-  const int my_last = min(prefix + q0 + min(lp, max(n_rows, 1) - 1), kv_len - 1);
+  const int my_last = min(prefix + q0 + min(pos, max(n_rows, 1) - 1), kv_len - 1);
   const int full_until = min(prefix + q0, kv_len - 1);
   const int32_t* table_row = a.kv.table + req * a.kv.table_row_stride;
   const uint32_t max_slot = (uint32_t)(a.kv.n_slots - 1);
   const uint32_t row_units = (uint32_t)(a.kv.slab_row_stride * 2 / 16);
-  const int head = kvh * G + rt0 + (two_blocks ? 0 : hw);  // (folded: kvh = 0 and G counts the heads of both halves)
+  const int head0 = kvh * G + rt0 + (two_blocks ? 0 : hw);  // (folded: kvh = 0 and G counts the heads of both halves)
+  const int head = head0 + hsub;                            // the q head of this lane's column
 
   // ---- Q^T fragments: lane (position lp, half hi) holds Q[q_row0 + lp][head][16 kb + 8 hi ..] ----
   uint4 qf[8];
   {
-    const char* qrow = (const char*)a.q + (q_row0 + lp) * a.q_row_stride * 2;
+    const char* qrow = (const char*)a.q + (q_row0 + pos) * a.q_row_stride * 2;
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
       qf[kb] = make_uint4(0, 0, 0, 0);
-      if (lp < n_rows) {
+      if (col_ok) {
         if (fold == 0) {
           qf[kb] = *(const uint4*)(qrow + ((int64_t)head * D + 16 * kb + 8 * hi) * 2);
         } else if ((16 * kb + 8 * hi) / 64 == head / fold) {
@@ -421,15 +432,18 @@ void prefill_mfma32_kernel(PrefillArgs a) {
 #pragma unroll
       for (int db = 0; db < 4; ++db) o_lds[(acc_row(r, 0) + 4 * hi) * kOPad + 32 * db + lp] = o_acc[db][r] * ir;
     }
-    for (int idx = lane; idx < n_rows * (D / 8); idx += 64) {
-      const int r = idx / (D / 8), c8 = idx % (D / 8);
+    for (int idx = lane; idx < 32 * (D / 8); idx += 64) {
+      const int r = idx / (D / 8), c8 = idx % (D / 8);  // r: column of S^T = (q head r / PW, position r % PW)
+      if (r % PW >= n_rows || r / PW >= n_heads) continue;
+      const int64_t orow = q_row0 + r % PW;
+      const int oh = head0 + r / PW;
       const float* src = o_lds + r * kOPad + c8 * 8;
       const uint4 packed = make_uint4(E::pack2(src[0], src[1]), E::pack2(src[2], src[3]),
                                       E::pack2(src[4], src[5]), E::pack2(src[6], src[7]));
       if (fold == 0) {
-        *(uint4*)((char*)a.out + ((q_row0 + r) * a.out_row_stride + (int64_t)head * D + c8 * 8) * 2) = packed;
-      } else if ((c8 * 8) / 64 == head / fold) {
-        *(uint4*)((char*)a.out + ((q_row0 + r) * a.out_row_stride + (int64_t)head * 64 + (c8 * 8) % 64) * 2) = packed;
+        *(uint4*)((char*)a.out + (orow * a.out_row_stride + (int64_t)oh * D + c8 * 8) * 2) = packed;
+      } else if ((c8 * 8) / 64 == oh / fold) {
+        *(uint4*)((char*)a.out + (orow * a.out_row_stride + (int64_t)oh * 64 + (c8 * 8) % 64) * 2) = packed;
       }
     }
   }
@@ -445,23 +459,32 @@ void prefill_mfma32_kernel(PrefillArgs a) {
 }  // namespace
 
 bool prefill_mfma32_supported(const PrefillArgs& a) {
-  return a.blk_rows == 64 && a.n_kv_heads > 0 && a.n_q_heads / a.n_kv_heads >= 2;
+  return (a.blk_rows == 64 || a.blk_rows == 16) && a.n_kv_heads > 0 && a.n_q_heads / a.n_kv_heads >= 2;
 }
 
-// the grid of paged_prefill_mfma.hip's launch with two q heads per workgroup
+// the grid of paged_prefill_mfma.hip's launch with 2 (64-position blocks) or 8 (16-position
+// blocks) q heads per workgroup
 hipError_t launch_prefill_mfma32(const PrefillArgs& a, hipStream_t stream) {
   const int group = a.n_q_heads / a.n_kv_heads;
-  const int n_z = (group + 1) / 2;
+  const int hpw = a.blk_rows == 64 ? 2 : 8;
+  const int n_z = (group + hpw - 1) / hpw;
   const int64_t local_groups = ((int64_t)a.max_groups * a.n_kv_heads + 7) / 8;
   const int64_t n_wg = 8 * local_groups * a.grp_blocks * n_z;
   if (n_wg > 0x7fffffffll) return hipErrorInvalidValue;
   dim3 grid((unsigned)n_wg, 1, 1);
-  const char* pad_e = getenv("BSGL_PREFILL_LDS_PAD");
+  const char* pad_e = getenv("BSGL_PREFILL_LDS_PAD");  // tuning aid: extra LDS per workgroup, to lower the occupancy
   const unsigned pad = pad_e != nullptr ? (unsigned)atoi(pad_e) : 0u;
-  if (a.dtype == kBF16)
-    hipLaunchKernelGGL((prefill_mfma32_kernel<bf16_tag>), grid, dim3(256), pad, stream, a);
-  else
-    hipLaunchKernelGGL((prefill_mfma32_kernel<f16_tag>), grid, dim3(256), 0, stream, a);
+  if (a.blk_rows == 64) {
+    if (a.dtype == kBF16)
+      hipLaunchKernelGGL((prefill_mfma32_kernel<bf16_tag, 32>), grid, dim3(256), pad, stream, a);
+    else
+      hipLaunchKernelGGL((prefill_mfma32_kernel<f16_tag, 32>), grid, dim3(256), pad, stream, a);
+  } else {
+    if (a.dtype == kBF16)
+      hipLaunchKernelGGL((prefill_mfma32_kernel<bf16_tag, 16>), grid, dim3(256), pad, stream, a);
+    else
+      hipLaunchKernelGGL((prefill_mfma32_kernel<f16_tag, 16>), grid, dim3(256), pad, stream, a);
+  }
   return hipGetLastError();
 }
 

@@ -539,6 +539,33 @@ def test_extend_over_many_page_table_blocks(gpu, dtype, hq, hkv, dim):
     assert bool(torch.isfinite(got).all()) and bool((err <= bound).all()), f"worst excess {(err - bound).max().item():.3e}"
 
 
+@pytest.mark.parametrize("dtype,hq,hkv,dim", [(torch.bfloat16, 28, 4, 128), (torch.float16, 12, 2, 128), (torch.bfloat16, 16, 2, 128),
+                                              (torch.float16, 14, 2, 64), (torch.bfloat16, 4, 2, 128)])
+def test_short_extends_share_one_stream(gpu, dtype, hq, hkv, dim):
+    """Batches of short extends (a few new tokens over long cached prefixes, as after prefix-cache
+    hits): 16-position workgroups that serve up to 8 q heads from one K/V stream.  Lengths of
+    1, 15, 16, 17 and 33 new tokens (one, one full, two and three blocks), an empty request, and a
+    mean below the switch to 64-position blocks."""
+    from baby_sglang_amd import _hip
+
+    ext = [1, 15, 16, 17, 33, 0, 8, 3, 16, 2]
+    prefix_lens = [0, 700, 1030, 5, 520, 40, 1500, 64, 0, 2047]
+    seq_lens = [p + e for p, e in zip(prefix_lens, ext)]
+    cpu, r2t, kv = random_decode_problem(gpu, dtype, hq, hkv, dim, seq_lens, seed=3 * hq + dim)
+    gen = torch.Generator().manual_seed(6)
+    q = torch.randn((sum(ext), hq, dim), generator=gen).to(dtype)
+    pl, el = torch.tensor(prefix_lens), torch.tensor(ext)
+    want = orc.prefill_exact(q, cpu["k_slab"], cpu["v_slab"], cpu["req_to_token"], cpu["req_pool_indices"], cpu["seq_lens"], pl, el)
+    spread = orc.prefill_exact(q, cpu["k_slab"], cpu["v_slab"].abs(), cpu["req_to_token"], cpu["req_pool_indices"], cpu["seq_lens"], pl, el)
+    k_slab, v_slab = kv.get_kv_buffer(0)
+    got = _hip.paged_prefill(q.to(gpu), k_slab, v_slab, r2t.req_to_token, cpu["req_pool_indices"].to(gpu),
+                             cpu["seq_lens"].to(gpu), pl.to(gpu), el.to(gpu), variant=2)
+    ulp = 2.0**-8 if dtype == torch.bfloat16 else 2.0**-11
+    err = (got.double().cpu() - want).abs()
+    bound = ulp * want.abs() + ulp * spread + 2e-4
+    assert bool(torch.isfinite(got).all()) and bool((err <= bound).all()), f"worst excess {(err - bound).max().item():.3e}"
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("slope", [0.02, 0.4])
 def test_extend_scores_rising_along_the_sequence(gpu, dtype, slope):
