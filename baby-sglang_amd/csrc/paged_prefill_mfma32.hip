@@ -1,5 +1,6 @@
 // Matrix-core paged extend (prefill) attention for gfx950 on the 32x32x16 product shape
-// (bf16 / f16, head_dim 128, at least two q heads per kv head, 64-position blocks).
+// (bf16 / f16, head_dim 128, at least two q heads per kv head; blocks of 64 positions, or of 16
+// for batches of short extends: see the PW parameter of the kernel).
 //
 // Same contract, work list, K/V streaming and LDS image as paged_prefill_mfma.hip (reference:
 // _prefill_attention, attn_backend.py:34-110); what differs is how a workgroup's 64 positions x
@@ -18,7 +19,7 @@
 //                                       IS the A operand (position on the lane, tokens in the
 //                                       registers -- the order of summation over tokens is free
 //                                       as long as the V fragment uses the same one)
-// The steps are software-pipelined inside the wave as in the 16-row kernel: iteration i turns
+// The steps are software-pipelined inside the wave (the 16-row kernel's are not): iteration i turns
 // scores i into probabilities while the matrix cores compute scores i + 1, then runs PV i.
 #include "bsgl_device.h"
 #include "bsgl_launch.h"
