@@ -65,8 +65,13 @@ using namespace mfma;
 
 // Two waves per SIMD (8 single-wave workgroups per CU, which is also what the LDS rings
 // allow): 256 registers per lane, which bounds how many partial rows the merge reads at once.
-template <typename Tag, int HPT, int NSTAGE, bool NT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2)))
+// W = waves per workgroup.  1: a piece is one wave's.  2 or 4 (launches with too few pieces to
+// give every SIMD a wave): the waves of a workgroup take the piece's tiles in turn, each through a
+// ring of its own -- a wave's tile rate is set by its 8 LDS-DMA instructions per tile, so W waves
+// stream a piece W times as fast -- and wave 0 adds up their (m, l, O) in LDS before the piece's
+// result is stored, so the number of parts the split merge sees does not grow.
+template <typename Tag, int HPT, int NSTAGE, bool NT, int W = 1>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2)))
 void decode_mfma_kernel(DecodeArgs a) {
   using E = Elem<Tag>;
   constexpr int D = 128;
@@ -78,13 +83,16 @@ void decode_mfma_kernel(DecodeArgs a) {
   static_assert(HPT == 1 || HPT == 2, "");
   static_assert((NSTAGE - 1) * DMA_PER_TILE < 64, "vmcnt is a 6-bit counter");
 
-  __shared__ __attribute__((aligned(1024))) char smem[RING + kSlotBlock * 4];
-  int32_t* s_slots = (int32_t*)(smem + RING);
+  static_assert(W == 1 || RING >= (HPT * 34) * 64 * 4, "a wave's state is handed over through its ring");
+  __shared__ __attribute__((aligned(1024))) char smem_all[W * RING + kSlotBlock * 4];
+  int32_t* s_slots = (int32_t*)(smem_all + W * RING);
+  const int lane = threadIdx.x & 63;
+  const int wave = W == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  char* smem = smem_all + wave * RING;  // this wave's ring
   const uint32_t lds_ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
-  const int lane = threadIdx.x;
   uint64_t* trace = nullptr;
-  if (a.trace != nullptr) {
+  if (a.trace != nullptr && wave == 0) {
     trace = a.trace + 8 * ((uint64_t)blockIdx.x + (uint64_t)gridDim.x * (blockIdx.y + (uint64_t)gridDim.y * blockIdx.z));
     uint32_t xcc, hw;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -239,7 +247,7 @@ void decode_mfma_kernel(DecodeArgs a) {
     const uint64_t new_row = piece_is_v ? (uint64_t)a.v_new + (uint64_t)row * a.v_new_stride * 2
                                         : (uint64_t)a.k_new + (uint64_t)row * a.k_new_stride * 2;
     lane_new_src = new_row + piece_off;
-    if (split == 0 && new_slot != kNewTok && lane < REC / 16) {
+    if (split == 0 && wave == 0 && new_slot != kNewTok && lane < REC / 16) {
       // copy this head group's new K and V rows into the slab (plain chunk order)
       const uint64_t o = (uint64_t)(head0 + piece_head) * (D * 2) + (uint64_t)(piece_chunk << 4);
       const uint4 val = *(const uint4*)(new_row + o);
@@ -286,32 +294,36 @@ void decode_mfma_kernel(DecodeArgs a) {
     // branches between them), then the LDS writes.  Written as a loop of load - write pairs the
     // compiler waits for every load before it issues the next: up to 8 memory round trips at
     // the head of every workgroup while HBM idles.
+    if (W > 1) __syncthreads();  // every wave is done with the previous block's entries
     {
+      const int tid = lane + 64 * wave;
       auto stage_entries = [&](auto n_c) {
         constexpr int N = decltype(n_c)::value;
         uint32_t ent[N];
 #pragma unroll
-        for (int j = 0; j < N; ++j) ent[j] = (uint32_t)table_row[blk + min(lane + 64 * j, n_blk - 1)];
+        for (int j = 0; j < N; ++j) ent[j] = (uint32_t)table_row[blk + min(tid + 64 * W * j, n_blk - 1)];
 #pragma unroll
         for (int j = 0; j < N; ++j) {
           uint32_t s = ent[j] > max_slot ? max_slot : ent[j];
           // row offset of the slot in 16-byte units (host checked that it stays below 2^32 - 1)
-          if (lane + 64 * j < n_blk) s_slots[lane + 64 * j] = (int32_t)(s == new_slot ? kNewTok : s * row_units);
+          if (tid + 64 * W * j < n_blk) s_slots[tid + 64 * W * j] = (int32_t)(s == new_slot ? kNewTok : s * row_units);
         }
       };
       static_assert(kSlotBlock == 512, "entries per lane below");
-      if (n_blk <= 128) stage_entries(std::integral_constant<int, 2>{});
-      else if (n_blk <= 256) stage_entries(std::integral_constant<int, 4>{});
-      else stage_entries(std::integral_constant<int, 8>{});
+      if (n_blk <= 128 * W) stage_entries(std::integral_constant<int, 2>{});
+      else if (n_blk <= 256 * W) stage_entries(std::integral_constant<int, (4 > 8 / W ? 8 / W : 4)>{});
+      else stage_entries(std::integral_constant<int, 8 / W>{});
     }
     // (same wave: the LDS writes above are ordered before the LDS reads below)
     // Retire every load the compiler knows about (q fragments, page-table entries)
     // HERE, with the builtin it models: inside the tile loop it must find nothing
     // of its own to wait for, or its vmcnt(0) would also drain the DMA prefetch.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
+    if (W > 1) __syncthreads();  // the entries were written by all waves
 
+    // (a wave's tiles: wave, wave + W, ...; its k-th tile goes through stage k % NSTAGE of its ring)
     auto issue_tile = [&](int tile) {
-      const uint32_t stage = lds_ring + (uint32_t)(tile % NSTAGE) * TILE_BYTES;
+      const uint32_t stage = lds_ring + (uint32_t)((tile / W) % NSTAGE) * TILE_BYTES;
       // lane j holds the row offset of token j of the tile; tokens past the end
       // re-read the last valid one (finite data, weight 0)
       const uint32_t tok_off = (uint32_t)s_slots[min(tile * kTile + (lane & 15), n_blk - 1)];
@@ -331,12 +343,12 @@ void decode_mfma_kernel(DecodeArgs a) {
 
 #pragma unroll
     for (int t = 0; t < NSTAGE - 1; ++t)
-      if (t < n_tiles) issue_tile(t);
+      if (wave + t * W < n_tiles) issue_tile(wave + t * W);
 
-    for (int tile = 0; tile < n_tiles; ++tile) {
-      const int ahead = n_tiles - 1 - tile;  // tiles issued after this one (capped below)
+    for (int tile = wave; tile < n_tiles; tile += W) {
+      const int ahead = (n_tiles - 1 - tile) / W;  // this wave's tiles after this one (capped below)
       if (ahead >= NSTAGE - 1) {
-        issue_tile(tile + NSTAGE - 1);
+        issue_tile(tile + (NSTAGE - 1) * W);
         dma_wait<(NSTAGE - 1) * DMA_PER_TILE>();
       } else if (NSTAGE > 3 && ahead == 2) {
         dma_wait<2 * DMA_PER_TILE>();
@@ -345,7 +357,7 @@ void decode_mfma_kernel(DecodeArgs a) {
       } else {
         dma_wait<0>();
       }
-      const char* st = smem + (tile % NSTAGE) * TILE_BYTES;
+      const char* st = smem + ((tile / W) % NSTAGE) * TILE_BYTES;
       const int n_valid = n_blk - tile * kTile;  // >= 1
 
 #pragma unroll
@@ -398,6 +410,49 @@ void decode_mfma_kernel(DecodeArgs a) {
     }
   }
 
+  if constexpr (W > 1) {
+    // ---- the workgroup's waves: states to wave 0 through LDS (each wave's own ring, idle now) --
+    // state of a wave and kv head: 34 floats per lane, float k of lane l at [k][l]
+    // (a wave's ring is its own and it has waited for its last tile)
+    if (wave != 0) {
+      float* stf = (float*)smem;
+#pragma unroll
+      for (int hh = 0; hh < HPT; ++hh) {
+        stf[(hh * 34 + 0) * 64 + lane] = m_run[hh];
+        stf[(hh * 34 + 1) * 64 + lane] = l_run[hh];
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) stf[(hh * 34 + 2 + 4 * n + r) * 64 + lane] = o_acc[hh][n][r];
+      }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    for (int w = 1; w < W; ++w) {
+      const float* stf = (const float*)(smem_all + w * RING);
+#pragma unroll
+      for (int hh = 0; hh < HPT; ++hh) {
+        const float mw = stf[(hh * 34 + 0) * 64 + lane], lw = stf[(hh * 34 + 1) * 64 + lane];
+        const float m_new = fmaxf(m_run[hh], mw);
+        // (a wave that saw no token has m = -inf and nothing to add: factor 0, never exp2(nan))
+        const float a0 = m_run[hh] == kNegInf ? 0.f : fast_exp2(m_run[hh] - m_new);
+        const float aw = mw == kNegInf ? 0.f : fast_exp2(mw - m_new);
+        m_run[hh] = m_new;
+        l_run[hh] = l_run[hh] * a0 + lw * aw;
+        float a0r[4], awr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          a0r[r] = __shfl(a0, 4 * lg + r);  // O rows are q = 4 g + r on lane group g
+          awr[r] = __shfl(aw, 4 * lg + r);
+        }
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            o_acc[hh][n][r] = o_acc[hh][n][r] * a0r[r] + stf[(hh * 34 + 2 + 4 * n + r) * 64 + lane] * awr[r];
+      }
+    }
+  }
   if (trace != nullptr && lane == 0) trace[2] = wall_clock64();
   // ---- finish: sum l over the lane groups, normalise, write ---------------------------
   const int64_t n_rh = (int64_t)a.rows * a.n_q_heads;
@@ -627,6 +682,23 @@ hipError_t launch_tag(const DecodeArgs& a, hipStream_t stream) {
   }
   if (stages == 4) return launch_inst<Tag, 1, 4>(a, stream);
   if (stages == 3) return launch_inst<Tag, 1, 3>(a, stream);
+  // Waves per workgroup: one where the pieces alone give every SIMD a wave (1024 on this chip),
+  // else two or four waves share a piece.
+  const int64_t n_pieces = (int64_t)a.rows * a.n_kv_heads * (a.balance_target > 0 ? a.balance_target : a.n_splits);
+  int waves = n_pieces > 512 ? 1 : n_pieces > 256 ? 2 : 4;
+  {
+    const int forced = env_int("BSGL_MFMA_WAVES", 0);  // tuning override
+    if (forced == 1 || forced == 2 || forced == 4) waves = forced;
+  }
+  if (waves > 1 && env_int("BSGL_MFMA_NT", 1)) {
+    dim3 grid(a.rows, a.n_kv_heads, a.n_splits);
+    if (a.balance_target > 0) grid = dim3((unsigned)((int64_t)a.rows * (a.balance_target + 1) * a.n_kv_heads), 1, 1);
+    if (waves == 2)
+      hipLaunchKernelGGL((decode_mfma_kernel<Tag, 1, 2, true, 2>), grid, dim3(128), 0, stream, a);
+    else
+      hipLaunchKernelGGL((decode_mfma_kernel<Tag, 1, 2, true, 4>), grid, dim3(256), 0, stream, a);
+    return hipGetLastError();
+  }
   return launch_inst<Tag, 1, 2>(a, stream);
 }
 

@@ -188,6 +188,40 @@ def test_decode_random_ragged(gpu, dtype, hq, hkv, dim, variant):
         assert torch.allclose(lse.double().cpu(), want_lse, rtol=1e-4, atol=2e-3 if dtype != torch.float32 else 1e-4)
 
 
+@pytest.mark.parametrize("waves", [1, 2, 4])
+@pytest.mark.parametrize("dtype,hq,hkv,dim", [(torch.bfloat16, 12, 2, 128), (torch.float16, 28, 4, 128), (torch.bfloat16, 14, 2, 64)])
+def test_pieces_shared_by_the_waves_of_a_workgroup(gpu, dtype, hq, hkv, dim, waves, monkeypatch):
+    """Small launches give a piece to two or four waves (tiles in turn, states added up in LDS):
+    every width against the oracle, on lengths that leave some waves without a tile (1, 16, 17
+    tokens), with a block border inside a piece (600, 1100 tokens in one piece) and with splits;
+    output, log-sum-exp and the fused write of the new token."""
+    from baby_sglang_amd import _hip
+
+    monkeypatch.setenv("BSGL_MFMA_WAVES", str(waves))
+    seq_lens = [1, 16, 17, 33, 600, 1100, 64, 2047]
+    cpu, r2t, kv = random_decode_problem(gpu, dtype, hq, hkv, dim, seq_lens, seed=11 * hq + waves)
+    gen = torch.Generator().manual_seed(8)
+    k_new = torch.randn((len(seq_lens), hkv, dim), generator=gen).to(dtype).to(gpu)
+    v_new = torch.randn((len(seq_lens), hkv, dim), generator=gen).to(dtype).to(gpu)
+    rows, seq = cpu["req_pool_indices"].to(gpu), cpu["seq_lens"].to(gpu)
+    loc = r2t.req_to_token[rows, seq - 1].contiguous()
+    k_ref, v_ref = cpu["k_slab"].clone(), cpu["v_slab"].clone()
+    orc.kv_scatter_ref(k_ref, v_ref, loc.cpu(), k_new.cpu(), v_new.cpu())
+    want, want_lse = orc.decode_exact(cpu["q"], k_ref, v_ref, cpu["req_to_token"], cpu["req_pool_indices"], cpu["seq_lens"],
+                                      return_lse=True)
+    for n_splits in (1, 4, 16):
+        kv.k_buffer[0].copy_(cpu["k_slab"])
+        kv.v_buffer[0].copy_(cpu["v_slab"])
+        k_slab, v_slab = kv.get_kv_buffer(0)
+        lse = torch.empty((len(seq_lens), hq), dtype=torch.float32, device=gpu)
+        out = _hip.paged_decode(cpu["q"].to(gpu), k_slab, v_slab, r2t.req_to_token, rows, seq, n_splits=n_splits, lse=lse,
+                                k_new=k_new, v_new=v_new, out_cache_loc=loc, fuse_kv_write=True)
+        torch.cuda.synchronize()
+        assert_close(out, want, dtype, f"waves={waves} splits={n_splits}")
+        assert torch.allclose(lse.double().cpu(), want_lse, rtol=1e-4, atol=2e-3)
+        assert torch.equal(k_slab.cpu(), k_ref) and torch.equal(v_slab.cpu(), v_ref)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("hq", [14, 4, 16])
 def test_two_kv_heads_of_64_on_the_matrix_core_kernel(gpu, dtype, hq):
