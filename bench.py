@@ -301,6 +301,45 @@ def cpu_baseline(args, budget_s):
     }
 
 
+def extend_extras(dev, reps=5):
+    """Extend (prefill) attention beside the headline: one layer call of a 7B-shaped chunked
+    prefill (128 requests, 512 new tokens over 1536 cached, Hq=28 / Hkv=4, bf16, random-permutation
+    page table) -- ms per layer call, TFLOP/s with flops = 4 Hq D (ext * prefix + ext (ext + 1) / 2)
+    per request, and the fraction of the dense bf16 MFMA peak (2.5 PFLOP/s)."""
+    import baby_sglang_amd as pkg
+
+    batch, ext, prefix, hq, hkv, dim = 128, 512, 1536, 28, 4, 128
+    seq = prefix + ext
+    gen = torch.Generator(device=dev).manual_seed(0)
+    kv = pkg.MHATokenToKVPool(batch * seq, torch.bfloat16, hkv, dim, 1, str(dev))
+    kv.arena.normal_(generator=gen)
+    r2t = pkg.ReqToTokenPool(batch, seq, str(dev))
+    r2t.req_to_token.copy_((torch.randperm(batch * seq, generator=gen, device=dev).to(torch.int32) + 1).view(batch, seq))
+    q = torch.randn((batch * ext, hq, dim), generator=gen, device=dev).to(torch.bfloat16)
+    rows = torch.arange(batch, device=dev)
+    seq_t = torch.full((batch,), seq, dtype=torch.int64, device=dev)
+    pre_t = torch.full((batch,), prefix, dtype=torch.int64, device=dev)
+    k_slab, v_slab = kv.get_kv_buffer(0)
+    ws = torch.empty(pkg._hip.prefill_workspace_bytes(batch, q.shape[0], hq, dim), dtype=torch.uint8, device=dev)
+    out = torch.empty((q.shape[0], hq * dim), dtype=torch.bfloat16, device=dev)
+
+    def call():
+        pkg._hip.paged_prefill(q, k_slab, v_slab, r2t.req_to_token, rows, seq_t, pre_t, seq_t - pre_t, out=out, workspace=ws)
+
+    call()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    flops = 4.0 * hq * dim * (ext * prefix + ext * (ext + 1) / 2) * batch
+    return {"extend_workload": "7B shapes: 128 requests x 512 new tokens over 1536 cached, Hq=28 Hkv=4 D=128 bf16, one layer call",
+            "extend_ms_per_layer": ms, "extend_tflops": flops / ms / 1e9, "extend_frac_of_bf16_mfma_peak": flops / ms / 1e9 / 2500.0}
+
+
 def read_traffic():
     """HBM bytes per decode launch from a committed rocprofv3 --pmc summary, if any."""
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -416,6 +455,10 @@ def main():
             if alt == "ragged":
                 extras["ragged_mean_seq"] = float(wl.local_seq.float().mean().item())
         wl.set_table(args.table)
+        try:
+            extras.update(extend_extras(dev))
+        except Exception as exc:  # a side measurement: it must not take the headline line with it
+            extras["extend_error"] = repr(exc)
         result["extras"] = extras
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
