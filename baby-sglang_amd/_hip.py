@@ -207,8 +207,13 @@ def paged_decode(
     out_cache_loc: Optional[torch.Tensor] = None,
     fuse_kv_write: bool = False,
     uniform_splits: bool = False,
+    _plan: Optional[tuple] = None,
 ) -> torch.Tensor:
     """softmax(q K^T * scale) V over page-table rows; returns [B, Hq * D].
+
+    (``_plan``: ``(workspace bytes needed, stream handle)`` from a caller that has looked them
+    up already for this shape and stream -- the per-layer call of the backend --, so that they
+    are not asked for again.)
 
     ``out_dtype=torch.float32`` returns unrounded results (with ``lse``, the
     state a cross-rank merge needs); default is q's dtype.  ``k_new`` /
@@ -245,7 +250,7 @@ def paged_decode(
         scale = 1.0 / math.sqrt(dim)
     if n_splits is None:
         n_splits = decode_num_splits(batch, hkv, req_to_token.shape[1])
-    need = decode_workspace_bytes(batch, hq, dim, n_splits, out_dtype != q.dtype)
+    need = _plan[0] if _plan is not None else decode_workspace_bytes(batch, hq, dim, n_splits, out_dtype != q.dtype)
     if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
         workspace = torch.zeros(need, dtype=torch.uint8, device=q.device)
     if uniform_splits:
@@ -276,7 +281,7 @@ def paged_decode(
         batch, hq, hkv, dim, scale, _dtype_code(q), _DTYPE_CODE[out_dtype], n_splits, variant,
         workspace.data_ptr() if need else None,
         workspace.numel() * workspace.element_size() if need else 0,
-        _stream_ptr(q.device),
+        _plan[1] if _plan is not None else _stream_ptr(q.device),
     )  # fmt: skip
     _check(rc, "bsgl_paged_decode")
     return out

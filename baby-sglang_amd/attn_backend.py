@@ -69,17 +69,28 @@ class SimpleAttentionBackend:
             q, k if write_kv else None, v if write_kv else None, forward_batch, layer_id
         )
 
+    # (batch, heads, dim, columns) -> (n_splits, workspace bytes): two library calls per shape, not per layer
+    _plans = {}
+
     @staticmethod
     def _decode_workspace(q, n_q_heads: int, n_kv_heads: int, max_ctx: int):
         batch, dim = q.shape[0], q.shape[-1]
-        n_splits = _hip.decode_num_splits(batch, n_kv_heads, max_ctx)
-        need = _hip.decode_workspace_bytes(batch, n_q_heads, dim, n_splits)
-        key = (q.device, torch.cuda.current_stream(q.device).cuda_stream)
+        shape = (batch, n_q_heads, n_kv_heads, dim, max_ctx)
+        plan = SimpleAttentionBackend._plans.get(shape)
+        if plan is None:
+            n_splits = _hip.decode_num_splits(batch, n_kv_heads, max_ctx)
+            plan = (n_splits, _hip.decode_workspace_bytes(batch, n_q_heads, dim, n_splits))
+            if len(SimpleAttentionBackend._plans) > 4096:
+                SimpleAttentionBackend._plans.clear()
+            SimpleAttentionBackend._plans[shape] = plan
+        n_splits, need = plan
+        stream = torch.cuda.current_stream(q.device).cuda_stream
+        key = (q.device, stream)
         ws = SimpleAttentionBackend._workspaces.get(key)
         if ws is None or ws.numel() < need:
             ws = _hip.new_decode_workspace(max(need, 1 << 20), q.device)
             SimpleAttentionBackend._workspaces[key] = ws
-        return n_splits, ws
+        return n_splits, ws, (need, stream)
 
     @staticmethod
     def _decode_attention(q, k, v, forward_batch: SimplifiedForwardBatch, layer_id: int):
@@ -88,7 +99,7 @@ class SimpleAttentionBackend:
             raise NotImplementedError("float8 KV cache write is not supported in baby-sglang MVP")
         k_slab, v_slab = pool.get_kv_buffer(layer_id)
         table = forward_batch.req_to_token_pool.req_to_token
-        n_splits, ws = SimpleAttentionBackend._decode_workspace(q, q.shape[1], k_slab.shape[1], table.shape[1])
+        n_splits, ws, plan = SimpleAttentionBackend._decode_workspace(q, q.shape[1], k_slab.shape[1], table.shape[1])
         return _hip.paged_decode(
             q,
             k_slab,
@@ -103,6 +114,7 @@ class SimpleAttentionBackend:
             v_new=v,
             out_cache_loc=forward_batch.out_cache_loc if k is not None else None,
             fuse_kv_write=SimpleAttentionBackend.fuse_decode_kv_write,
+            _plan=plan,
         )
 
     @staticmethod

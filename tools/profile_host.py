@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Host-side cost of one decode layer call through SimpleAttentionBackend.forward: cProfile of
+bench.py's backend_step (28 calls per step) with the GPU kept busy, top functions by own time."""
+import cProfile
+import os
+import pstats
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    sys.argv = [sys.argv[0], "--cpu-seconds", "0", "--no-extras"]
+    args = bench.parse_args()
+    dev = torch.device("cuda", 0)
+    import baby_sglang_amd as pkg
+
+    layout = pkg.TPLayout(0, 1, 12, 2)
+    wl = bench.Workload(args, dev, layout)
+    for _ in range(3):
+        wl.backend_step()
+    torch.cuda.synchronize()
+    # host time alone: issue without waiting for the GPU in between (the queue absorbs 50 steps)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        wl.backend_step()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"backend.forward: {(t1 - t0) / 20 / args.layers * 1e6:.1f} us of host time per layer call; with the GPU: {(t2 - t0) / 20 / args.layers * 1e6:.1f} us")
+    t0 = time.perf_counter()
+    for _ in range(20):
+        wl.step()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    print(f"_hip.paged_decode directly: {(t1 - t0) / 20 / args.layers * 1e6:.1f} us of host time per layer call")
+    prof = cProfile.Profile()
+    prof.enable()
+    for _ in range(20):
+        wl.backend_step()
+    prof.disable()
+    torch.cuda.synchronize()
+    pstats.Stats(prof).sort_stats("tottime").print_stats(18)
+
+
+if __name__ == "__main__":
+    main()
