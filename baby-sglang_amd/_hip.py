@@ -34,6 +34,7 @@ DECODE_FUSE_KV_WRITE = 0x100  # caller asserts: out_cache_loc slots belong to th
 DECODE_UNIFORM_SPLITS = 0x200  # exactly n_splits equal pieces per request instead of length-balanced ones
 
 _DTYPE_CODE = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
+_DTYPE_CODE_GET = _DTYPE_CODE.get
 
 # every symbol include/bsgl_attn.h declares, with its ctypes signature
 _vp, _i64, _i32, _f32, _sz = (
@@ -226,44 +227,58 @@ def paged_decode(
     one batch-wide length unless ``uniform_splits`` asks for exactly ``n_splits``
     equal pieces per request.
     """
+    # (this wrapper runs once per layer and decode step beside a ~30 us kernel: every tensor's
+    # shape and strides are asked for once)
     _need_gpu(q, k_slab, v_slab, req_to_token, req_pool_indices, seq_lens)
     q = _rows(q)
+    q_dtype = q.dtype
     batch, hq, dim = q.shape
-    hkv = k_slab.shape[1]
+    k_shape, k_stride0 = k_slab.shape, k_slab.stride(0)
+    hkv = k_shape[1]
     if out_dtype is None:
-        out_dtype = out.dtype if out is not None else q.dtype
+        out_dtype = out.dtype if out is not None else q_dtype
     if out is None:
         out = torch.empty((batch, hq * dim), dtype=out_dtype, device=q.device)
     if batch == 0:
         return out
-    if k_slab.dtype != q.dtype or v_slab.dtype != q.dtype:
-        raise ValueError(f"q is {q.dtype} but the KV slabs are {k_slab.dtype}")
-    if k_slab.stride(0) != v_slab.stride(0):
+    if k_slab.dtype != q_dtype or v_slab.dtype != q_dtype:
+        raise ValueError(f"q is {q_dtype} but the KV slabs are {k_slab.dtype}")
+    if k_stride0 != v_slab.stride(0):
         raise ValueError("K and V slabs must share a row stride")
     if req_pool_indices.dtype != torch.int64:
         req_pool_indices = req_pool_indices.to(torch.int64)
     if seq_lens.dtype != torch.int64:
         seq_lens = seq_lens.to(torch.int64)
-    if req_to_token.dtype != torch.int32 or req_to_token.stride(1) != 1:
+    t_shape, t_stride = req_to_token.shape, req_to_token.stride()
+    if req_to_token.dtype != torch.int32 or t_stride[1] != 1:
         raise ValueError("req_to_token must be int32 with unit column stride")
     if scale is None:
         scale = 1.0 / math.sqrt(dim)
     if n_splits is None:
-        n_splits = decode_num_splits(batch, hkv, req_to_token.shape[1])
-    need = _plan[0] if _plan is not None else decode_workspace_bytes(batch, hq, dim, n_splits, out_dtype != q.dtype)
-    if need and (workspace is None or workspace.numel() * workspace.element_size() < need):
-        workspace = torch.zeros(need, dtype=torch.uint8, device=q.device)
+        n_splits = decode_num_splits(batch, hkv, t_shape[1])
+    need = _plan[0] if _plan is not None else decode_workspace_bytes(batch, hq, dim, n_splits, out_dtype != q_dtype)
+    ws_bytes = 0
+    if need:
+        if workspace is not None:
+            ws_bytes = workspace.numel() * workspace.element_size()
+        if ws_bytes < need:
+            workspace = torch.zeros(need, dtype=torch.uint8, device=q.device)
+            ws_bytes = need
     if uniform_splits:
         variant |= DECODE_UNIFORM_SPLITS
+    q_code = _DTYPE_CODE_GET(q_dtype)
+    if q_code is None:
+        raise NotImplementedError(f"dtype {q_dtype} has no HIP attention kernel")
     new = (None, None, 0, 0, None)
     if k_new is not None or v_new is not None or out_cache_loc is not None:
         if k_new is None or v_new is None or out_cache_loc is None:
             raise ValueError("k_new, v_new and out_cache_loc go together")
         k_new = _rows(k_new.view(batch, hkv, dim) if k_new.dim() == 2 else k_new)
         v_new = _rows(v_new.view(batch, hkv, dim) if v_new.dim() == 2 else v_new)
-        if k_new.dtype != q.dtype or v_new.dtype != q.dtype:
+        if k_new.dtype != q_dtype or v_new.dtype != q_dtype:
             raise ValueError("new K/V rows must have q's dtype")
-        if tuple(k_new.shape) != (batch, hkv, dim) or tuple(v_new.shape) != (batch, hkv, dim):
+        want = (batch, hkv, dim)
+        if tuple(k_new.shape) != want or tuple(v_new.shape) != want:
             raise ValueError("new K/V rows must be [batch, n_kv_heads, head_dim]")
         loc = out_cache_loc if out_cache_loc.dtype == torch.int32 else out_cache_loc.to(torch.int32)
         loc = loc if loc.is_contiguous() else loc.contiguous()
@@ -275,12 +290,11 @@ def paged_decode(
     rc = lib.bsgl_paged_decode(
         out.data_ptr(), out.stride(0), lse.data_ptr() if lse is not None else None,
         q.data_ptr(), q.stride(0), *new,
-        k_slab.data_ptr(), v_slab.data_ptr(), k_slab.stride(0), k_slab.shape[0],
-        req_to_token.data_ptr(), req_to_token.stride(0), req_to_token.shape[0], req_to_token.shape[1],
+        k_slab.data_ptr(), v_slab.data_ptr(), k_stride0, k_shape[0],
+        req_to_token.data_ptr(), t_stride[0], t_shape[0], t_shape[1],
         req_pool_indices.data_ptr(), seq_lens.data_ptr(),
-        batch, hq, hkv, dim, scale, _dtype_code(q), _DTYPE_CODE[out_dtype], n_splits, variant,
-        workspace.data_ptr() if need else None,
-        workspace.numel() * workspace.element_size() if need else 0,
+        batch, hq, hkv, dim, scale, q_code, _DTYPE_CODE[out_dtype], n_splits, variant,
+        workspace.data_ptr() if need else None, ws_bytes,
         _plan[1] if _plan is not None else _stream_ptr(q.device),
     )  # fmt: skip
     _check(rc, "bsgl_paged_decode")
