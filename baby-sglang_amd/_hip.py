@@ -133,15 +133,25 @@ def _stream_ptr(device: torch.device) -> int:
 
 def _rows(x: torch.Tensor) -> torch.Tensor:
     """[T, heads, dim] (or [T, heads*dim]) view whose inner dims are dense."""
-    if x.dim() == 3:
-        if x.stride(2) != 1 or x.stride(1) != x.shape[2]:
+    return _rows3(x)[0]
+
+
+def _rows3(x: torch.Tensor):
+    """``_rows`` plus the result's shape and strides (asked for once: a stride() call costs as
+    much as the rest of the check)."""
+    sh, st = x.shape, x.stride()
+    n = len(sh)
+    if n == 3:
+        if st[2] != 1 or st[1] != sh[2]:
             x = x.contiguous()
-    elif x.dim() == 2:
-        if x.stride(1) != 1:
+            st = x.stride()
+    elif n == 2:
+        if st[1] != 1:
             x = x.contiguous()
+            st = x.stride()
     else:
-        raise ValueError(f"expected a 2-D or 3-D tensor, got shape {tuple(x.shape)}")
-    return x
+        raise ValueError(f"expected a 2-D or 3-D tensor, got shape {tuple(sh)}")
+    return x, sh, st
 
 
 def kv_scatter(k_slab, v_slab, loc, k_new, v_new) -> None:
@@ -230,9 +240,9 @@ def paged_decode(
     # (this wrapper runs once per layer and decode step beside a ~30 us kernel: every tensor's
     # shape and strides are asked for once)
     _need_gpu(q, k_slab, v_slab, req_to_token, req_pool_indices, seq_lens)
-    q = _rows(q)
+    q, q_shape, q_stride = _rows3(q)
     q_dtype = q.dtype
-    batch, hq, dim = q.shape
+    batch, hq, dim = q_shape
     k_shape, k_stride0 = k_slab.shape, k_slab.stride(0)
     hkv = k_shape[1]
     if out_dtype is None:
@@ -273,23 +283,23 @@ def paged_decode(
     if k_new is not None or v_new is not None or out_cache_loc is not None:
         if k_new is None or v_new is None or out_cache_loc is None:
             raise ValueError("k_new, v_new and out_cache_loc go together")
-        k_new = _rows(k_new.view(batch, hkv, dim) if k_new.dim() == 2 else k_new)
-        v_new = _rows(v_new.view(batch, hkv, dim) if v_new.dim() == 2 else v_new)
+        k_new, kn_shape, kn_stride = _rows3(k_new.view(batch, hkv, dim) if k_new.dim() == 2 else k_new)
+        v_new, vn_shape, vn_stride = _rows3(v_new.view(batch, hkv, dim) if v_new.dim() == 2 else v_new)
         if k_new.dtype != q_dtype or v_new.dtype != q_dtype:
             raise ValueError("new K/V rows must have q's dtype")
         want = (batch, hkv, dim)
-        if tuple(k_new.shape) != want or tuple(v_new.shape) != want:
+        if tuple(kn_shape) != want or tuple(vn_shape) != want:
             raise ValueError("new K/V rows must be [batch, n_kv_heads, head_dim]")
         loc = out_cache_loc if out_cache_loc.dtype == torch.int32 else out_cache_loc.to(torch.int32)
         loc = loc if loc.is_contiguous() else loc.contiguous()
         if loc.shape[0] != batch:
             raise ValueError("out_cache_loc must have one slot per request")
-        new = (k_new.data_ptr(), v_new.data_ptr(), k_new.stride(0), v_new.stride(0), loc.data_ptr())
+        new = (k_new.data_ptr(), v_new.data_ptr(), kn_stride[0], vn_stride[0], loc.data_ptr())
         if fuse_kv_write:
             variant |= DECODE_FUSE_KV_WRITE
     rc = lib.bsgl_paged_decode(
         out.data_ptr(), out.stride(0), lse.data_ptr() if lse is not None else None,
-        q.data_ptr(), q.stride(0), *new,
+        q.data_ptr(), q_stride[0], *new,
         k_slab.data_ptr(), v_slab.data_ptr(), k_stride0, k_shape[0],
         req_to_token.data_ptr(), t_stride[0], t_shape[0], t_shape[1],
         req_pool_indices.data_ptr(), seq_lens.data_ptr(),
