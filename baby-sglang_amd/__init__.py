@@ -15,6 +15,7 @@ from .qwen2_hip import BabyQwen2ForCausalLM
 from .tp_runtime import (
     TPLayout,
     init_tp,
+    split_tp_groups,
     tp_all_gather,
     tp_all_reduce_sum,
     tp_attention_exchange,
@@ -31,6 +32,7 @@ __all__ = [
     "ReqToTokenPool",
     "TPLayout",
     "init_tp",
+    "split_tp_groups",
     "tp_all_gather",
     "tp_all_reduce_sum",
     "tp_attention_exchange",

@@ -55,6 +55,30 @@ def init_tp(backend: Optional[str] = None) -> Tuple[int, int, object]:
     return rank, world_size, tp_group
 
 
+_REPLICA_GROUPS = {}
+
+
+def split_tp_groups(tp_size: int, world_group=None):
+    """Cut the job into ``world // tp_size`` independent tensor-parallel groups of
+    consecutive ranks (replicas that serve different requests: requests are independent, so
+    nothing is exchanged between replicas).  Returns ``(tp_group, tp_rank, replica, n_replicas)``.
+    Every rank creates every group, in the same order, as ``new_group`` demands."""
+    if not dist.is_initialized():
+        if tp_size != 1:
+            raise ValueError("a tensor-parallel group of more than one rank needs an initialised process group")
+        return None, 0, 0, 1
+    world = dist.get_world_size(group=world_group)
+    rank = dist.get_rank(group=world_group)
+    if tp_size < 1 or world % tp_size:
+        raise ValueError(f"tp_size {tp_size} does not divide the world of {world}")
+    if tp_size == world:
+        return (world_group if world_group is not None else dist.group.WORLD), rank, 0, 1
+    key = (world, tp_size)
+    if key not in _REPLICA_GROUPS:
+        _REPLICA_GROUPS[key] = [dist.new_group(list(range(g * tp_size, (g + 1) * tp_size))) for g in range(world // tp_size)]
+    return _REPLICA_GROUPS[key][rank // tp_size], rank % tp_size, rank // tp_size, world // tp_size
+
+
 def _world(tp_group) -> int:
     if not dist.is_initialized():
         return 1

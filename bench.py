@@ -55,6 +55,10 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-fuse", action="store_true", help="KV write as its own launch instead of inside the decode kernel")
     ap.add_argument("--no-extras", action="store_true", help="skip the contiguous-table and eager/graph side measurements")
+    ap.add_argument("--tp", type=int, default=0,
+                    help="ranks per tensor-parallel group (0 = the kv-head count, 2 for these shapes, or N if smaller); "
+                         "N / tp groups run side by side as replicas on different requests.  --tp N puts all N "
+                         "ranks in one group (kv heads first, then sequence slices)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1 GPUs: weak = N x batch requests over the tensor-parallel group (per-GPU KV bytes fixed), "
                          "strong = the same batch cut N ways")
@@ -75,7 +79,7 @@ class Workload:
         self.hq, self.hkv, self.dim = 12, 2, 128
         self.hq_l, self.hkv_l = layout.local_q_heads, layout.local_kv_heads
         self.dtype = torch.bfloat16
-        gen = torch.Generator(device=dev).manual_seed(1234 + layout.rank)
+        gen = torch.Generator(device=dev).manual_seed(1234 + getattr(args, "seed_rank", layout.rank))
         # this rank's share of every request's tokens (round-robin by position when tp_seq > 1)
         seq = torch.full((B,), S, dtype=torch.int64, device=dev)
         self.local_seq = layout.local_len(seq)
@@ -359,23 +363,35 @@ def main():
         args.gpus = world
     import baby_sglang_amd as pkg
 
-    rank, world, tp_group = pkg.init_tp()
+    rank, world, world_group = pkg.init_tp()
     dev = torch.device("cuda", torch.cuda.current_device())
     per_gpu_batch = args.batch
-    if world > 1 and args.scaling == "weak":
-        # tensor parallel over all requests of the job: every rank holds its kv-head / sequence
-        # share of N x batch requests, i.e. the KV bytes of `batch` whole requests
-        args.batch *= world
-    layout = pkg.TPLayout(rank, world, 12, 2)
+    # Tensor parallel up to the kv-head count (each rank owns whole kv heads: one all-gather of the
+    # output rows per layer); beyond it the job grows by replicas of that group on other requests,
+    # which are independent and exchange nothing.  --tp N makes one group of all ranks instead
+    # (sequence slices inside a kv head: an all-to-all of partial states as well).
+    tp = args.tp if args.tp > 0 else min(world, 2)
+    tp_group, tp_rank, replica, n_replicas = pkg.split_tp_groups(tp, world_group)
+    if args.scaling == "weak":
+        # every rank holds its kv-head / sequence share of tp x batch requests, i.e. the KV bytes
+        # of `batch` whole requests
+        args.batch *= tp
+    elif n_replicas > 1:
+        if args.batch % n_replicas:
+            raise SystemExit("--scaling strong: the batch must divide over the replicas")
+        args.batch //= n_replicas
+    layout = pkg.TPLayout(tp_rank, tp, 12, 2)
+    args.seed_rank = rank  # replicas hold different requests
+    job_batch = args.batch * n_replicas
     wl = Workload(args, dev, layout)
 
-    if world > 1:
+    if tp > 1:
         args.mode = "eager"  # collectives are issued by torch.distributed from Python each layer
     runner = make_runner(wl, args.mode, tp_group)
     dt = timed_steps(runner, args.steps, args.warmup, world)
     event_ms_per_step = LAST_EVENT_MS[0] / args.steps
     ms_per_step = dt / args.steps * 1e3
-    tokens_per_s = args.batch * args.steps / dt
+    tokens_per_s = job_batch * args.steps / dt
 
     result = {
         "metric": "decode tokens/s, paged-attention path, Qwen2.5-1.5B shapes bs=64 seq=2048",
@@ -391,14 +407,17 @@ def main():
         "dtype": "bf16",
         "data": "synthetic (N(0,1) q/k/v and KV slabs, random-permutation page table, torch.manual_seed)",
         "config": {
-            "workload": f"BASELINE configs[2]: Qwen2.5-1.5B bf16 decode, batch={args.batch}, seq={args.seq}, "
+            "workload": f"BASELINE configs[2]: Qwen2.5-1.5B bf16 decode, batch={job_batch}, seq={args.seq}, "
                         f"{args.layers} layers x (KV write + paged decode attention), Hq=12 Hkv=2 D=128, "
                         f"page table={args.table}, kv_layout={args.kv_layout}",
-            "global_batch": args.batch,
-            "kv_bytes_per_gpu_equal_to_batch": per_gpu_batch if args.scaling == "weak" or world == 1 else args.batch / world,
+            "global_batch": job_batch,
+            "kv_bytes_per_gpu_equal_to_batch": per_gpu_batch if args.scaling == "weak" or world == 1 else job_batch / world,
             "seq_len": args.seq,
             "parallelism": "single GPU" if world == 1 else
-                           f"tp{world} = {layout.tp_kv} kv-head shards x {layout.tp_seq} sequence slices, one all-gather per layer",
+                           f"{n_replicas} replica(s) x tp{tp} ({layout.tp_kv} kv-head shards x {layout.tp_seq} sequence slices); "
+                           + ("no exchange" if tp == 1 else
+                              "one all-gather of the output rows per layer inside each tp group" if layout.tp_seq == 1 else
+                              "per layer an all-to-all of partial states inside each kv head's ranks and an all-gather of the merged rows"),
             "launch": args.mode,
             "n_splits": wl.n_splits,
             "decode_variant": args.variant,
@@ -412,7 +431,7 @@ def main():
         # this is the kernel time plus the ~1.5 us boundary between dependent launches (an upper
         # bound on what rocprofv3 reports for the kernel alone).  With several GPUs the region also
         # holds the collectives, so the launches are timed on their own there.
-        if world == 1:
+        if tp == 1:
             ev_ms = event_ms_per_step / args.layers
         else:
             ev_ms = kernel_event_times(wl, max(2, min(args.steps, 10)))
@@ -433,7 +452,7 @@ def main():
             "avg_launch_us": ev_ms * 1e3,
         }
         result["step_hbm_gbs"] = total_b * args.layers / (ms_per_step * 1e-3) / 1e9
-        if world > 1:
+        if tp > 1:
             # the exchange step broken out: decode launches alone vs the whole step
             result["attention_only_ms_per_step"] = ev_ms * args.layers
             result["exchange_ms_per_step"] = max(0.0, ms_per_step - ev_ms * args.layers)

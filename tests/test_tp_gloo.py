@@ -97,6 +97,43 @@ def test_four_ranks_two_kv_shards_of_two_sequence_slices():
     mp.spawn(_worker, args=(4, _free_port(), 2), nprocs=4, join=True)
 
 
+def _replica_worker(rank, world, port):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from baby_sglang_amd import tp_runtime as tp
+
+    r, w, world_group = tp.init_tp(backend="gloo")
+    group, tp_rank, replica, n_replicas = tp.split_tp_groups(2, world_group)
+    assert (tp_rank, replica, n_replicas) == (rank % 2, rank // 2, world // 2)
+    assert dist.get_world_size(group=group) == 2 and dist.get_rank(group=group) == tp_rank
+    # head-sharded exchange inside each replica, on the replica's own rows
+    layout = tp.TPLayout(tp_rank, 2, 4, 2)
+    rows, dim = 3, 8
+    full = torch.arange(rows * 4 * dim, dtype=torch.float64).view(rows, 4, dim) + 1000.0 * replica
+    got = tp.tp_attention_exchange(layout, layout.shard_q(full).reshape(rows, -1).contiguous(), None, group, torch.float64)
+    assert torch.equal(got, full.view(rows, -1))
+    # sums stay inside a replica
+    x = torch.tensor([float(rank)])
+    tp.tp_all_reduce_sum(x, group)
+    assert x.item() == float(4 * replica + 1)
+    # one group of all ranks: the world group itself
+    g_all, r_all, rep, n_rep = tp.split_tp_groups(world, world_group)
+    assert (r_all, rep, n_rep) == (rank, 0, 1) and dist.get_world_size(group=g_all) == world
+    with pytest.raises(ValueError):
+        tp.split_tp_groups(3, world_group)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_ranks_as_two_replicas_of_a_two_rank_group():
+    """world 4 = 2 replicas x tp 2: each pair shards the kv heads of its own requests and
+    gathers its own rows; nothing crosses between replicas."""
+    mp.spawn(_replica_worker, args=(4, _free_port()), nprocs=4, join=True)
+
+
 def test_layouts():
     import sys
 
