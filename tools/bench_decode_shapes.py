@@ -14,7 +14,8 @@ sys.path.insert(0, ROOT)
 import baby_sglang_amd as pkg  # noqa: E402
 from baby_sglang_amd import _hip  # noqa: E402
 
-MODELS = {"0.5b": (14, 2, 64), "1.5b": (12, 2, 128), "7b": (28, 4, 128)}
+# "1.5b-tp2": one rank's share of a two-rank tensor-parallel group (one kv head and its 6 q heads)
+MODELS = {"0.5b": (14, 2, 64), "1.5b": (12, 2, 128), "7b": (28, 4, 128), "1.5b-tp2": (6, 1, 128)}
 
 
 def run(model, batch, seq, layers, reps, dev):
@@ -62,7 +63,7 @@ def run(model, batch, seq, layers, reps, dev):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / reps / layers * 1e3
     nbytes = 2 * batch * seq * hkv * dim * 2 + batch * seq * 4 + 2 * batch * hq * dim * 2 + 2 * batch * hkv * dim * 2
-    print(f"{model:5s} batch {batch:4d} seq {seq:6d} splits<= {n_splits:2d}: {us:8.2f} us/layer  "
+    print(f"{model:8s} batch {batch:4d} seq {seq:6d} splits<= {n_splits:2d}: {us:8.2f} us/layer  "
           f"{nbytes / us / 1e6:6.2f} TB/s = {nbytes / us / 1e6 / 8:.3f} of peak  ({batch / (us * 28) * 1e6:,.0f} tokens/s at 28 layers)", flush=True)
     del kv, graph
     torch.cuda.empty_cache()
