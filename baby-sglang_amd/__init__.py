@@ -20,6 +20,7 @@ from .tp_runtime import (
     tp_all_reduce_sum,
     tp_attention_exchange,
     tp_broadcast,
+    use_capi_collectives,
 )
 
 __all__ = [
@@ -37,4 +38,5 @@ __all__ = [
     "tp_all_reduce_sum",
     "tp_attention_exchange",
     "tp_broadcast",
+    "use_capi_collectives",
 ]

@@ -28,6 +28,8 @@ BSGL_ERR_BAD_ARG = -1
 BSGL_ERR_UNSUPPORTED = -2
 BSGL_ERR_HIP = -3
 BSGL_ERR_WORKSPACE = -4
+BSGL_ERR_COMM = -5
+COMM_ID_BYTES = 128
 
 DECODE_AUTO, DECODE_VALU, DECODE_MFMA = 0, 1, 2
 DECODE_FUSE_KV_WRITE = 0x100  # caller asserts: out_cache_loc slots belong to their own request only
@@ -77,6 +79,12 @@ SIGNATURES = {
         ctypes.c_int,
         [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
     ),
+    "bsgl_comm_unique_id": (ctypes.c_int, [_vp]),
+    "bsgl_comm_init": (ctypes.c_int, [_i32, _i32, _vp]),
+    "bsgl_comm_world": (ctypes.c_int, []),
+    "bsgl_all_reduce_sum": (ctypes.c_int, [_vp, _i64, _i32, _vp]),
+    "bsgl_all_gather": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "bsgl_comm_destroy": (ctypes.c_int, []),
 }
 
 
@@ -467,3 +475,53 @@ def rope_kv_write(
     )  # fmt: skip
     _check(rc, "bsgl_rope_kv_write")
     return q, k, v
+
+
+# ---- tensor-parallel collectives on RCCL through the C ABI -------------------------------------
+
+
+def comm_unique_id() -> bytes:
+    """A fresh communicator id (rank 0 makes it; every rank of the group passes the same bytes
+    to ``comm_init``)."""
+    buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+    _check(lib.bsgl_comm_unique_id(buf), "bsgl_comm_unique_id")
+    return buf.raw
+
+
+def comm_init(rank: int, world: int, unique_id: bytes) -> None:
+    """This process's communicator, on the current HIP device; blocks until every rank has called."""
+    if len(unique_id) != COMM_ID_BYTES:
+        raise ValueError(f"unique id must be {COMM_ID_BYTES} bytes")
+    _check(lib.bsgl_comm_init(rank, world, ctypes.c_char_p(unique_id)), "bsgl_comm_init")
+
+
+def comm_world() -> int:
+    return int(lib.bsgl_comm_world())
+
+
+def comm_destroy() -> None:
+    _check(lib.bsgl_comm_destroy(), "bsgl_comm_destroy")
+
+
+def all_reduce_sum(x: torch.Tensor) -> torch.Tensor:
+    """In-place sum over the communicator's ranks, on the caller's current stream."""
+    _need_gpu(x)
+    if not x.is_contiguous():
+        raise ValueError("all_reduce_sum needs a contiguous tensor")
+    _check(lib.bsgl_all_reduce_sum(x.data_ptr(), x.numel(), _dtype_code(x), _stream_ptr(x.device)), "bsgl_all_reduce_sum")
+    return x
+
+
+def all_gather(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``[world * x.shape[0], ...]``: every rank's ``x`` in rank order, on the caller's current stream."""
+    _need_gpu(x)
+    world = comm_world()
+    if world < 1:
+        raise ValueError("all_gather: no communicator (comm_init first)")
+    x = x.contiguous()
+    if out is None:
+        out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    elif out.numel() != world * x.numel() or out.dtype != x.dtype or not out.is_contiguous():
+        raise ValueError("all_gather: out must be contiguous, of x's dtype and world times its size")
+    _check(lib.bsgl_all_gather(out.data_ptr(), x.data_ptr(), x.numel(), _dtype_code(x), _stream_ptr(x.device)), "bsgl_all_gather")
+    return out

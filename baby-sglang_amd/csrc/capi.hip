@@ -26,6 +26,15 @@ int hip_fail(const char* what, hipError_t e) {
   return fail(BSGL_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
 }
 
+}  // namespace
+
+namespace bsgl {
+// error reporting for the other translation units of the C surface (comm.hip)
+int set_error(int code, const char* msg) { return fail(code, "%s", msg); }
+}  // namespace bsgl
+
+namespace {
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

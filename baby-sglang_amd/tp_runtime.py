@@ -79,6 +79,39 @@ def split_tp_groups(tp_size: int, world_group=None):
     return _REPLICA_GROUPS[key][rank // tp_size], rank % tp_size, rank // tp_size, world // tp_size
 
 
+_CAPI_GROUP = [None, False]  # (the group whose collectives go through the library's RCCL communicator, active)
+
+
+def use_capi_collectives(tp_group) -> None:
+    """Route ``tp_all_gather`` / ``tp_all_reduce_sum`` of GPU tensors over ``tp_group`` through the
+    HIP library's own RCCL communicator (``bsgl_comm_init`` / ``bsgl_all_gather`` /
+    ``bsgl_all_reduce_sum``) instead of ``torch.distributed``: the calls only enqueue on the
+    current stream -- no work objects, no host wait -- so a whole step, collectives included, can
+    be replayed from a HIP graph.  The communicator id travels over the group's existing
+    ``torch.distributed`` store (one broadcast at set-up); one communicator per process."""
+    from . import _hip
+
+    if not dist.is_initialized():
+        raise ValueError("use_capi_collectives needs an initialised process group for the id hand-over")
+    rank, world = dist.get_rank(group=tp_group), dist.get_world_size(group=tp_group)
+    box = [_hip.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(tp_group, 0) if tp_group is not None else 0, group=tp_group)
+    _hip.comm_init(rank, world, box[0])
+    _CAPI_GROUP[0], _CAPI_GROUP[1] = tp_group, True
+
+
+def release_capi_collectives() -> None:
+    from . import _hip
+
+    if _CAPI_GROUP[1]:
+        _hip.comm_destroy()
+    _CAPI_GROUP[0], _CAPI_GROUP[1] = None, False
+
+
+def _capi(x: torch.Tensor, tp_group) -> bool:
+    return _CAPI_GROUP[1] and x.is_cuda and (tp_group is _CAPI_GROUP[0] or tp_group == _CAPI_GROUP[0])
+
+
 def _world(tp_group) -> int:
     if not dist.is_initialized():
         return 1
@@ -88,6 +121,10 @@ def _world(tp_group) -> int:
 def tp_all_reduce_sum(x: torch.Tensor, tp_group) -> torch.Tensor:
     if _world(tp_group) == 1:
         return x
+    if _capi(x, tp_group) and x.is_contiguous():
+        from . import _hip
+
+        return _hip.all_reduce_sum(x)
     dist.all_reduce(x, op=dist.ReduceOp.SUM, group=tp_group)
     return x
 
@@ -96,6 +133,10 @@ def tp_all_gather(x: torch.Tensor, tp_group) -> torch.Tensor:
     world = _world(tp_group)
     if world == 1:
         return x
+    if _capi(x, tp_group):
+        from . import _hip
+
+        return _hip.all_gather(x)
     out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     if x.is_cuda and dist.get_backend(tp_group) == "gloo":
         # gloo has no device all-gather: stage through host memory (rehearsals only; RCCL is the GPU path)

@@ -59,6 +59,10 @@ def parse_args():
                     help="ranks per tensor-parallel group (0 = the kv-head count, 2 for these shapes, or N if smaller); "
                          "N / tp groups run side by side as replicas on different requests.  --tp N puts all N "
                          "ranks in one group (kv heads first, then sequence slices)")
+    ap.add_argument("--collectives", choices=["torch", "capi"], default="torch",
+                    help="N > 1: torch = torch.distributed (RCCL) issued from Python per layer; capi = the library's own "
+                         "RCCL communicator (bsgl_all_gather on the launch stream), which lets --mode graph replay the "
+                         "whole step, collectives included (kv-head shards only)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1 GPUs: weak = N x batch requests over the tensor-parallel group (per-GPU KV bytes fixed), "
                          "strong = the same batch cut N ways")
@@ -385,7 +389,10 @@ def main():
     job_batch = args.batch * n_replicas
     wl = Workload(args, dev, layout)
 
-    if tp > 1:
+    if tp > 1 and args.collectives == "capi" and layout.tp_seq == 1:
+        pkg.use_capi_collectives(tp_group)  # enqueue-only collectives: the step can be captured
+    elif tp > 1:
+        args.collectives = "torch"
         args.mode = "eager"  # collectives are issued by torch.distributed from Python each layer
     runner = make_runner(wl, args.mode, tp_group)
     dt = timed_steps(runner, args.steps, args.warmup, world)
@@ -419,6 +426,7 @@ def main():
                               "one all-gather of the output rows per layer inside each tp group" if layout.tp_seq == 1 else
                               "per layer an all-to-all of partial states inside each kv head's ranks and an all-gather of the merged rows"),
             "launch": args.mode,
+            "collectives": args.collectives if tp > 1 else None,
             "n_splits": wl.n_splits,
             "decode_variant": args.variant,
         },
@@ -487,6 +495,7 @@ def main():
         print(json.dumps(result))
     if world > 1:
         torch.distributed.barrier()
+        pkg.tp_runtime.release_capi_collectives()
         torch.distributed.destroy_process_group()
 
 

@@ -37,6 +37,7 @@ extern "C" {
 #define BSGL_ERR_UNSUPPORTED (-2) /* dtype / head_dim / group size without a kernel */
 #define BSGL_ERR_HIP (-3)         /* a HIP runtime call failed */
 #define BSGL_ERR_WORKSPACE (-4)   /* workspace missing or too small */
+#define BSGL_ERR_COMM (-5)        /* RCCL missing or an RCCL call failed */
 
 /* element types of q / k / v / out / KV slabs */
 #define BSGL_DTYPE_BF16 0
@@ -229,6 +230,28 @@ int bsgl_rope_kv_write(void* q_out /*device*/, int64_t q_out_row_stride,
                        const int32_t* out_cache_loc /*device, [n_tok], or NULL*/,
                        int32_t n_tok, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim,
                        int32_t dtype, void* stream);
+
+/*
+ * Tensor-parallel collectives on RCCL (xGMI), one communicator per process (one process per
+ * GPU).  They stand behind the reference's torch.distributed wrappers: bsgl_comm_init behind
+ * init_tp (tp_runtime.py:10-24; the unique id made by rank 0 with bsgl_comm_unique_id reaches
+ * the other ranks by the caller's own means, e.g. the launcher's store), bsgl_all_reduce_sum
+ * behind tp_all_reduce_sum (tp_runtime.py:27-33, in place), bsgl_all_gather behind
+ * tp_all_gather (tp_runtime.py:36-44: rank r's `count_per_rank` elements land at
+ * out + r * count_per_rank, i.e. concatenation along dim 0).  The communicator is made on the
+ * CURRENT HIP device; collectives are enqueued on `stream` and return at once (no host wait:
+ * they may be captured into a HIP graph behind the attention launches).  RCCL is loaded on the
+ * first bsgl_comm_* call only (librccl.so.1); BSGL_ERR_COMM when it is missing or a call fails.
+ * bsgl_comm_init blocks until every rank of the group has called it.
+ */
+#define BSGL_COMM_ID_BYTES 128
+int bsgl_comm_unique_id(void* id_out /*host, BSGL_COMM_ID_BYTES*/);
+int bsgl_comm_init(int32_t rank, int32_t world, const void* unique_id /*host, BSGL_COMM_ID_BYTES*/);
+int bsgl_comm_world(void); /* ranks of the live communicator, 0 if none */
+int bsgl_all_reduce_sum(void* buf /*device, count elements, in place*/, int64_t count, int32_t dtype, void* stream);
+int bsgl_all_gather(void* out /*device, world * count_per_rank*/, const void* in /*device*/,
+                    int64_t count_per_rank, int32_t dtype, void* stream);
+int bsgl_comm_destroy(void);
 
 #ifdef __cplusplus
 }

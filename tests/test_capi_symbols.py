@@ -55,3 +55,16 @@ def test_bad_arguments_are_rejected_on_the_host():
     assert rc == _hip.BSGL_ERR_BAD_ARG
     # empty work is a successful no-op
     assert lib.bsgl_kv_scatter(None, None, 0, 0, None, None, None, 0, 0, 0, 2, 128, 0, None) == 0
+
+
+def test_collectives_reject_bad_arguments_without_a_communicator():
+    lib = _hip.lib
+    assert lib.bsgl_comm_world() == 0
+    assert lib.bsgl_all_reduce_sum(None, 4, 0, None) == _hip.BSGL_ERR_BAD_ARG and b"null" in lib.bsgl_last_error()
+    assert lib.bsgl_all_reduce_sum(None, 4, 9, None) == _hip.BSGL_ERR_UNSUPPORTED
+    assert lib.bsgl_all_gather(None, None, -1, 0, None) == _hip.BSGL_ERR_BAD_ARG
+    assert lib.bsgl_all_gather(None, None, 0, 0, None) == 0  # nothing to move
+    assert lib.bsgl_comm_init(2, 2, None) == _hip.BSGL_ERR_BAD_ARG and b"rank" in lib.bsgl_last_error()
+    assert lib.bsgl_comm_init(0, 1, None) == _hip.BSGL_ERR_BAD_ARG and b"id" in lib.bsgl_last_error()
+    assert lib.bsgl_comm_unique_id(None) == _hip.BSGL_ERR_BAD_ARG
+    assert lib.bsgl_comm_destroy() == 0  # no communicator: nothing to do
