@@ -59,10 +59,13 @@ def parse_args():
                     help="ranks per tensor-parallel group (0 = the kv-head count, 2 for these shapes, or N if smaller); "
                          "N / tp groups run side by side as replicas on different requests.  --tp N puts all N "
                          "ranks in one group (kv heads first, then sequence slices)")
-    ap.add_argument("--collectives", choices=["torch", "capi"], default="torch",
+    ap.add_argument("--collectives", choices=["auto", "torch", "capi"], default="auto",
                     help="N > 1: torch = torch.distributed (RCCL) issued from Python per layer; capi = the library's own "
-                         "RCCL communicator (bsgl_all_gather on the launch stream), which lets --mode graph replay the "
-                         "whole step, collectives included (kv-head shards only)")
+                         "RCCL communicator (bsgl_all_gather enqueued on the launch stream, no per-call work objects; "
+                         "kv-head shards only); auto = capi when its communicator comes up on every rank and its first "
+                         "gather equals torch.distributed's, torch otherwise")
+    ap.add_argument("--tp-graph", action="store_true",
+                    help="N > 1 with capi collectives: replay the whole step, collectives included, from one HIP graph")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1 GPUs: weak = N x batch requests over the tensor-parallel group (per-GPU KV bytes fixed), "
                          "strong = the same batch cut N ways")
@@ -348,6 +351,35 @@ def extend_extras(dev, reps=5):
             "extend_ms_per_layer": ms, "extend_tflops": flops / ms / 1e9, "extend_frac_of_bf16_mfma_peak": flops / ms / 1e9 / 2500.0}
 
 
+CAPI_NOTE = [None]
+
+
+def try_capi_collectives(pkg, tp_group, world_group, tp_rank, dev):
+    """Bring up the library's own RCCL communicator for this rank's tensor-parallel group and
+    check its first all-gather against torch.distributed's; every rank of the job learns whether
+    ALL ranks succeeded (one MIN all-reduce), so the ranks always agree on the path taken."""
+    dist = torch.distributed
+    ok = 1
+    try:
+        pkg.use_capi_collectives(tp_group)
+        probe = torch.full((4, 8), float(tp_rank + 1), device=dev, dtype=torch.bfloat16)
+        got = pkg._hip.all_gather(probe)
+        want = torch.empty_like(got)
+        dist.all_gather_into_tensor(want, probe, group=tp_group)
+        torch.cuda.synchronize()
+        if not torch.equal(got, want):
+            ok, CAPI_NOTE[0] = 0, "the library's all-gather disagreed with torch.distributed's"
+    except Exception as exc:  # RCCL missing, communicator refused, ...: the torch.distributed path remains
+        ok, CAPI_NOTE[0] = 0, repr(exc)[:300]
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev if dist.get_backend(world_group) != "gloo" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=world_group)
+    if int(flag.item()) == 0:
+        pkg.tp_runtime.release_capi_collectives()
+        pkg._hip.comm_destroy()
+        return False
+    return True
+
+
 def read_traffic():
     """HBM bytes per decode launch from a committed rocprofv3 --pmc summary, if any."""
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -389,11 +421,15 @@ def main():
     job_batch = args.batch * n_replicas
     wl = Workload(args, dev, layout)
 
-    if tp > 1 and args.collectives == "capi" and layout.tp_seq == 1:
-        pkg.use_capi_collectives(tp_group)  # enqueue-only collectives: the step can be captured
-    elif tp > 1:
-        args.collectives = "torch"
-        args.mode = "eager"  # collectives are issued by torch.distributed from Python each layer
+    collectives_note = None
+    if tp > 1:
+        want_capi = args.collectives in ("auto", "capi") and layout.tp_seq == 1
+        args.collectives = "capi" if want_capi and try_capi_collectives(pkg, tp_group, world_group, tp_rank, dev) else "torch"
+        if want_capi and args.collectives == "torch":
+            collectives_note = CAPI_NOTE[0] or "another rank could not bring up the library's communicator"
+        # torch.distributed calls are issued from Python each layer; the library's own enqueue-only
+        # collectives may also be captured with the step
+        args.mode = "graph" if (args.collectives == "capi" and args.tp_graph) else "eager"
     runner = make_runner(wl, args.mode, tp_group)
     dt = timed_steps(runner, args.steps, args.warmup, world)
     event_ms_per_step = LAST_EVENT_MS[0] / args.steps
@@ -427,6 +463,7 @@ def main():
                               "per layer an all-to-all of partial states inside each kv head's ranks and an all-gather of the merged rows"),
             "launch": args.mode,
             "collectives": args.collectives if tp > 1 else None,
+            "collectives_note": collectives_note,
             "n_splits": wl.n_splits,
             "decode_variant": args.variant,
         },
