@@ -204,21 +204,46 @@ void decode_mfma_kernel(DecodeArgs a) {
   const uint32_t max_slot = (uint32_t)(a.kv.n_slots - 1);
   const uint32_t row_units = (uint32_t)(a.kv.slab_row_stride * 2 / 16);
 
+  // ---- page-table entries of a block: requested (all loads together, clamped to the block so
+  // that nothing branches on a lane's own index between them), later turned into row offsets
+  // and written to LDS.  As a loop of load - write pairs the compiler waits for every load
+  // before it issues the next: up to 8 memory round trips at the head of a workgroup.
+  static_assert(kSlotBlock == 512, "entries per lane below");
+  constexpr int NE = 8 / W;  // entries per lane of a full block
+  const int tid = lane + 64 * wave;
+  auto request_entries = [&](int blk, int n_blk, uint32_t (&ent)[NE]) {
+#pragma unroll
+    for (int j = 0; j < NE; ++j)
+      if (64 * W * j < n_blk) ent[j] = (uint32_t)table_row[blk + min(tid + 64 * W * j, n_blk - 1)];
+  };
+  // The FIRST block's entries are requested here, together with the query fragments and the
+  // new token's slot and rows below, so that everything this workgroup needs before its first
+  // K/V request comes back in ONE memory round trip (requested inside the block loop they
+  // left only after the new slot had arrived: a second trip, 0.7 us of a 29 us launch).
+  uint32_t ent[NE];
+  if (start < end) request_entries(start, min(kSlotBlock, end - start), ent);
+
   // ---- Q^T fragments: lane (q = lq, g = lg) holds Q[q][32 s + 8 g .. +8], zero for pad columns
   uint4 qf[HPT][4];
   {
+    // One predicated load per fragment, address and predicate chosen by selects: written as
+    // branches on `fold` the compiler put a wait for ALL pending loads in front of every
+    // second fragment load (the branches' stores to the fragment registers met at a join),
+    // i.e. two more memory round trips before the first K/V request.
     const char* qrow = (const char*)a.q + (int64_t)row * a.q_row_stride * 2;
+    const int my_half = fold != 0 ? lq / fold : 0;  // folded heads: the half of the 128-wide row q head lq owns
 #pragma unroll
     for (int hh = 0; hh < HPT; ++hh)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
+        const int col = 32 * s + 8 * lg;  // first of this lane's 8 values of the row
+        // folded heads: q head lq's 64 values stand in the half of the row that its kv head owns
+        const int64_t plain = ((int64_t)(head0 + hh) * G + lq) * D + col;
+        const int64_t folded = (int64_t)lq * 64 + (col & 63);
+        const bool want_it = lq < G && (fold == 0 || (col >> 6) == my_half);
+        const uint4* src = (const uint4*)(qrow + (fold == 0 ? plain : folded) * 2);
         qf[hh][s] = make_uint4(0, 0, 0, 0);
-        if (fold == 0) {
-          if (lq < G) qf[hh][s] = *(const uint4*)(qrow + (((int64_t)(head0 + hh) * G + lq) * D + 32 * s + 8 * lg) * 2);
-        } else if (lq < G && (32 * s + 8 * lg) / 64 == lq / fold) {
-          // folded heads: q head lq's 64 values stand in the half of the 128-wide row that its kv head owns
-          qf[hh][s] = *(const uint4*)(qrow + ((int64_t)lq * 64 + (32 * s + 8 * lg) % 64) * 2);
-        }
+        if (want_it) qf[hh][s] = *src;
       }
   }
   const float scale_log2e = a.scale * kLog2e;
@@ -242,15 +267,19 @@ void decode_mfma_kernel(DecodeArgs a) {
   uint32_t new_slot = kNewTok;
   uint64_t lane_new_src = 0;
   if (fuse_kv) {
-    const int32_t loc = a.new_loc[row];
-    if (loc >= 0 && (uint32_t)loc <= max_slot) new_slot = (uint32_t)loc;
     const uint64_t new_row = piece_is_v ? (uint64_t)a.v_new + (uint64_t)row * a.v_new_stride * 2
                                         : (uint64_t)a.k_new + (uint64_t)row * a.k_new_stride * 2;
     lane_new_src = new_row + piece_off;
-    if (split == 0 && wave == 0 && new_slot != kNewTok && lane < REC / 16) {
+    // (the new rows are requested before the slot is, and the slot is looked at after both:
+    // one round trip)
+    const bool writer = split == 0 && wave == 0 && lane < REC / 16;
+    const uint64_t o = (uint64_t)(head0 + piece_head) * (D * 2) + (uint64_t)(piece_chunk << 4);
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (writer) val = *(const uint4*)(new_row + o);
+    const int32_t loc = a.new_loc[row];
+    if (loc >= 0 && (uint32_t)loc <= max_slot) new_slot = (uint32_t)loc;
+    if (writer && new_slot != kNewTok) {
       // copy this head group's new K and V rows into the slab (plain chunk order)
-      const uint64_t o = (uint64_t)(head0 + piece_head) * (D * 2) + (uint64_t)(piece_chunk << 4);
-      const uint4 val = *(const uint4*)(new_row + o);
       char* slab = piece_is_v ? (char*)a.kv.v_slab : (char*)a.kv.k_slab;
       *(uint4*)(slab + (uint64_t)new_slot * row_units * 16 + o) = val;
     }
@@ -290,29 +319,17 @@ void decode_mfma_kernel(DecodeArgs a) {
   for (int blk = start; blk < end; blk += kSlotBlock) {
     const int n_blk = min(kSlotBlock, end - blk);
     const int n_tiles = (n_blk + kTile - 1) / kTile;
-    // The block's page-table entries: all loads first (clamped to the block, so that nothing
-    // branches between them), then the LDS writes.  Written as a loop of load - write pairs the
-    // compiler waits for every load before it issues the next: up to 8 memory round trips at
-    // the head of every workgroup while HBM idles.
+    // The block's page-table entries (the first block's were requested before the query
+    // fragments): row offsets into LDS.
     if (W > 1) __syncthreads();  // every wave is done with the previous block's entries
-    {
-      const int tid = lane + 64 * wave;
-      auto stage_entries = [&](auto n_c) {
-        constexpr int N = decltype(n_c)::value;
-        uint32_t ent[N];
+    if (blk != start) request_entries(blk, n_blk, ent);
 #pragma unroll
-        for (int j = 0; j < N; ++j) ent[j] = (uint32_t)table_row[blk + min(tid + 64 * W * j, n_blk - 1)];
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-          uint32_t s = ent[j] > max_slot ? max_slot : ent[j];
-          // row offset of the slot in 16-byte units (host checked that it stays below 2^32 - 1)
-          if (tid + 64 * W * j < n_blk) s_slots[tid + 64 * W * j] = (int32_t)(s == new_slot ? kNewTok : s * row_units);
-        }
-      };
-      static_assert(kSlotBlock == 512, "entries per lane below");
-      if (n_blk <= 128 * W) stage_entries(std::integral_constant<int, 2>{});
-      else if (n_blk <= 256 * W) stage_entries(std::integral_constant<int, (4 > 8 / W ? 8 / W : 4)>{});
-      else stage_entries(std::integral_constant<int, 8 / W>{});
+    for (int j = 0; j < NE; ++j) {
+      if (tid + 64 * W * j < n_blk) {
+        const uint32_t e = ent[j] > max_slot ? max_slot : ent[j];
+        // row offset of the slot in 16-byte units (host checked that it stays below 2^32 - 1)
+        s_slots[tid + 64 * W * j] = (int32_t)(e == new_slot ? kNewTok : e * row_units);
+      }
     }
     // (same wave: the LDS writes above are ordered before the LDS reads below)
     // Retire every load the compiler knows about (q fragments, page-table entries)
