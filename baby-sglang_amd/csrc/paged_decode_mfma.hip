@@ -108,6 +108,38 @@ void decode_mfma_kernel(DecodeArgs a) {
   const int n_hg = a.n_kv_heads / HPT;  // head groups
   int row = blockIdx.x, hg = blockIdx.y, split = blockIdx.z, n_parts = a.n_splits;
   int flat_req = -1, flat_seq = 0;  // the row's page-table row and length, when found by the flat search
+  // flat grid: lane i's request length and page-table row, requested first so that the
+  // lane-only arithmetic below runs while they travel
+  auto len_of = [&](int i) {
+    const int64_t s64 = i < a.rows ? a.seq_lens[i] : 0;
+    const int64_t cap = a.kv.table_cols < (1 << 20) ? a.kv.table_cols : (1 << 20);
+    return (int)(s64 < 0 ? 0 : (s64 > cap ? cap : s64));
+  };
+  auto req_of = [&](int i) {
+    const int64_t r64 = i < a.rows ? a.req_idx[i] : 0;
+    return (int)(r64 < 0 ? 0 : (r64 >= a.kv.table_rows ? a.kv.table_rows - 1 : r64));
+  };
+  int len0 = 0, req0 = 0;
+  if (a.balance_target > 0) {
+    len0 = len_of(lane);
+    req0 = req_of(lane);
+  }
+  const int lq = lane & 15;   // q head (column of S^T / row of O) or d column
+  const int lg = lane >> 4;   // lane group
+  // ---- per-lane LDS read offsets -----------------------------------------------------
+  // K rows (A operand): lane (t = lq, g = lg) reads chunk 4 s + g of token t
+  const int k_rec = rec_of_token(lq);
+  int k_off[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) k_off[s] = k_rec * REC + (((4 * s + lg) ^ xr_of_rec(k_rec)) << 4);
+  // V blocks (B operand, transposed read): lane 4 q + p of group g addresses token 4 g + q,
+  // 8-byte piece p of the 32 bytes of d-tile n
+  const int v_rec = rec_of_token(4 * lg + ((lane >> 2) & 3));
+  int v_off[8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n)
+    v_off[n] = v_rec * REC + HPT * 256 + (((2 * n + ((lane >> 1) & 1)) ^ xr_of_rec(v_rec)) << 4) + ((lane & 1) << 3);
+
   if (a.balance_target > 0) {
     // ---- flat grid: which (row, piece) is this? -------------------------------------
     // (head group fastest: the workgroups of a piece's kv heads run side by side and read the
@@ -121,18 +153,7 @@ void decode_mfma_kernel(DecodeArgs a) {
     // workgroups; in descending order they cancel (1.2 % of the step).  Placement only.
     hg = n_hg - 1 - (int)(blockIdx.x % (unsigned)n_hg);
     const int piece = (int)(blockIdx.x / (unsigned)n_hg);
-    // per-lane request data, 64 rows at a time; the first block is loaded once for both passes
-    auto len_of = [&](int i) {
-      const int64_t s64 = i < a.rows ? a.seq_lens[i] : 0;
-      const int64_t cap = a.kv.table_cols < (1 << 20) ? a.kv.table_cols : (1 << 20);
-      return (int)(s64 < 0 ? 0 : (s64 > cap ? cap : s64));
-    };
-    auto req_of = [&](int i) {
-      const int64_t r64 = i < a.rows ? a.req_idx[i] : 0;
-      return (int)(r64 < 0 ? 0 : (r64 >= a.kv.table_rows ? a.kv.table_rows - 1 : r64));
-    };
-    const int len0 = len_of(lane);
-    const int req0 = req_of(lane);
+    // per-lane request data, 64 rows at a time; the first block was loaded above, once for both passes
     int tot = 0, longest = 0;
     for (int r0 = 0; r0 < a.rows; r0 += 64) {
       const int s = r0 == 0 ? len0 : len_of(r0 + lane);
@@ -180,8 +201,6 @@ void decode_mfma_kernel(DecodeArgs a) {
   // the row (the scores are then exactly the 64-wide ones) and only that half of its output row
   // is kept.  Partial results stay 128 wide.
   const int fold = a.fold_group;
-  const int lq = lane & 15;   // q head (column of S^T / row of O) or d column
-  const int lg = lane >> 4;   // lane group
 
   // ---- this row's token range (multiples of the tile so splits start on tiles) ----
   int64_t req;
@@ -284,20 +303,6 @@ void decode_mfma_kernel(DecodeArgs a) {
       *(uint4*)(slab + (uint64_t)new_slot * row_units * 16 + o) = val;
     }
   }
-
-  // ---- per-lane LDS read offsets -----------------------------------------------------
-  // K rows (A operand): lane (t = lq, g = lg) reads chunk 4 s + g of token t
-  const int k_rec = rec_of_token(lq);
-  int k_off[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) k_off[s] = k_rec * REC + (((4 * s + lg) ^ xr_of_rec(k_rec)) << 4);
-  // V blocks (B operand, transposed read): lane 4 q + p of group g addresses token 4 g + q,
-  // 8-byte piece p of the 32 bytes of d-tile n
-  const int v_rec = rec_of_token(4 * lg + ((lane >> 2) & 3));
-  int v_off[8];
-#pragma unroll
-  for (int n = 0; n < 8; ++n)
-    v_off[n] = v_rec * REC + HPT * 256 + (((2 * n + ((lane >> 1) & 1)) ^ xr_of_rec(v_rec)) << 4) + ((lane & 1) << 3);
 
   if (trace != nullptr && lane == 0) {
     trace[1] = wall_clock64();
