@@ -392,6 +392,12 @@ def read_traffic():
 
 def main():
     args = parse_args()
+    # stdout carries the ONE JSON line and nothing else: RCCL prints a five-line version banner on
+    # stdout when a communicator comes up (every rank), so file descriptor 1 is pointed at stderr
+    # for the run and the line goes out through a copy of the original descriptor.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.getenv("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -529,7 +535,8 @@ def main():
         result["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
 
     if rank == 0:
-        print(json.dumps(result))
+        json_out.write(json.dumps(result) + "\n")
+        json_out.flush()
     if world > 1:
         torch.distributed.barrier()
         pkg.tp_runtime.release_capi_collectives()
