@@ -63,6 +63,18 @@ namespace {
 
 using namespace mfma;
 
+// x / d for 0 <= x < 2^22, 0 < d < 2^22, exact: one reciprocal, one multiply and a step either
+// way (the product is within one of the quotient).  The compiler's 32-bit division is three times
+// as many instructions, and the piece search below is a chain of them on a workgroup's way to
+// its first K/V request.
+__device__ __forceinline__ int small_div(int x, int d) {
+  int q = (int)((float)x * __builtin_amdgcn_rcpf((float)d));
+  const int r = x - q * d;
+  q += r >= d ? 1 : 0;
+  q -= r < 0 ? 1 : 0;
+  return q;
+}
+
 // Two waves per SIMD (8 single-wave workgroups per CU, which is also what the LDS rings
 // allow): 256 registers per lane, which bounds how many partial rows the merge reads at once.
 // W = waves per workgroup.  1: a piece is one wave's.  2 or 4 (launches with too few pieces to
@@ -151,9 +163,28 @@ void decode_mfma_kernel(DecodeArgs a) {
     // than those on even ones, and so do the workgroups of head group 1 compared with head
     // group 0, whichever index they have.  In ascending order the two fall on the same
     // workgroups; in descending order they cancel (1.2 % of the step).  Placement only.
-    hg = n_hg - 1 - (int)(blockIdx.x % (unsigned)n_hg);
-    const int piece = (int)(blockIdx.x / (unsigned)n_hg);
+    // (the flat grid has at most rows * (target + 1) * n_hg <= 1024 * 65 * n_hg workgroups: small_div's range)
+    const int piece = __builtin_amdgcn_readfirstlane(small_div((int)blockIdx.x, n_hg));
+    hg = n_hg - 1 - ((int)blockIdx.x - piece * n_hg);
     // per-lane request data, 64 rows at a time; the first block was loaded above, once for both passes
+    // Equal lengths (every lane of a batch of at most 64 rows holds the same length): the answer
+    // in closed form.  The most pieces wanted per request never exceed n_splits, so the piece
+    // length is ceil(len / target) rounded up to tiles, every request yields at most `target`
+    // pieces, and the search below would stop at its first pass with exactly this result.
+    const int len_first = __builtin_amdgcn_readfirstlane(len0);
+    const bool equal_lens = a.rows <= 64 && a.balance_target <= a.n_splits && len_first < (1 << 22) &&
+                            __all(lane >= a.rows || len0 == len_first);
+    if (equal_lens) {
+      int piece_len = small_div(len_first + a.balance_target - 1, a.balance_target);
+      piece_len = max(kTile, (piece_len + kTile - 1) / kTile * kTile);
+      const int parts = __builtin_amdgcn_readfirstlane(min(a.n_splits, max(1, small_div(len_first + piece_len - 1, piece_len))));
+      row = __builtin_amdgcn_readfirstlane(small_div(piece, parts));
+      if (row >= a.rows) return;  // past the batch's last piece
+      split = piece - row * parts;
+      n_parts = parts;
+      flat_seq = len_first;
+      flat_req = __builtin_amdgcn_readlane(req0, row);
+    } else {
     int tot = 0, longest = 0;
     for (int r0 = 0; r0 < a.rows; r0 += 64) {
       const int s = r0 == 0 ? len0 : len_of(r0 + lane);
@@ -192,6 +223,7 @@ void decode_mfma_kernel(DecodeArgs a) {
       piece_len = (piece_len + kTile - 1) / kTile * kTile;
     }
     if (row < 0) return;  // past the batch's last piece
+    }
   }
   const int head0 = hg * HPT;
   const int G = a.n_q_heads / a.n_kv_heads;

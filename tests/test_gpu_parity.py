@@ -339,6 +339,30 @@ def test_length_balanced_splits(gpu, dtype):
             assert int(ws[: _hip.lib.bsgl_decode_counter_bytes()].max()) == 0
 
 
+@pytest.mark.parametrize("length", [1, 15, 16, 777, 2048])
+def test_equal_lengths_take_the_closed_form_of_the_piece_search(gpu, length, monkeypatch):
+    """A batch of at most 64 requests of ONE length finds its pieces in closed form instead of the
+    wave-wide search.  Both must cut a request the same way: the first rows of a 65-request batch
+    of that length (searched: more than 64 rows) and the same rows as a batch of their own
+    (closed form) give the same bits, for every split count, and agree with the oracle."""
+    from baby_sglang_amd import _hip
+
+    # (one wave per piece whatever the batch: small launches otherwise share a piece among
+    # several waves, which changes the order of the sums, not the pieces)
+    monkeypatch.setenv("BSGL_MFMA_WAVES", "1")
+    hq, hkv, dim, dtype = 12, 2, 128, torch.bfloat16
+    cpu, r2t, kv = random_decode_problem(gpu, dtype, hq, hkv, dim, [length] * 65, seed=77 + length)
+    want = orc.decode_exact(cpu["q"], cpu["k_slab"], cpu["v_slab"], cpu["req_to_token"], cpu["req_pool_indices"], cpu["seq_lens"])
+    k_slab, v_slab = kv.get_kv_buffer(0)
+    q, rows, seq = cpu["q"].to(gpu), cpu["req_pool_indices"].to(gpu), cpu["seq_lens"].to(gpu)
+    for n_splits in (16, 7, 2):
+        searched = _hip.paged_decode(q, k_slab, v_slab, r2t.req_to_token, rows, seq, n_splits=n_splits, variant=2)
+        assert_close(searched, want, dtype, f"65 rows of {length}, splits {n_splits}")
+        for n in (1, 9, 64):
+            closed = _hip.paged_decode(q[:n], k_slab, v_slab, r2t.req_to_token, rows[:n], seq[:n], n_splits=n_splits, variant=2)
+            assert torch.equal(closed, searched[:n]), f"{n} rows of {length}, splits {n_splits}"
+
+
 def test_decode_empty_and_zero_length(gpu):
     from baby_sglang_amd import _hip
 
