@@ -192,7 +192,7 @@ void decode_mfma_kernel(DecodeArgs a) {
       longest = max(longest, __builtin_amdgcn_readlane(wave_inclusive_scan<ScanMax>(s), 63));
     }
     const int want = a.rows * a.balance_target;
-    int piece_len = max((tot + want - 1) / want, (longest + a.n_splits - 1) / a.n_splits);
+    int piece_len = max((tot + want - 1) / want, small_div(longest + a.n_splits - 1, a.n_splits));  // (lengths are capped at 2^20)
     piece_len = max(kTile, (piece_len + kTile - 1) / kTile * kTile);
     // Rounding up per request can leave up to `rows` pieces more than wanted: a few CUs would
     // then hold one workgroup more than the others and finish a quarter later (ragged batches:
@@ -203,7 +203,7 @@ void decode_mfma_kernel(DecodeArgs a) {
       row = -1;
       for (int r0 = 0; r0 < a.rows; r0 += 64) {
         const int s = r0 == 0 ? len0 : len_of(r0 + lane);
-        const int parts = r0 + lane < a.rows ? min(a.n_splits, max(1, (s + piece_len - 1) / piece_len)) : 0;
+        const int parts = r0 + lane < a.rows ? min(a.n_splits, max(1, small_div(s + piece_len - 1, piece_len))) : 0;
         const int incl = wave_inclusive_scan<ScanAdd>(parts);
         const int blk_total = __builtin_amdgcn_readlane(incl, 63);
         if (row < 0 && piece < base + blk_total) {
@@ -226,7 +226,7 @@ void decode_mfma_kernel(DecodeArgs a) {
     }
   }
   const int head0 = hg * HPT;
-  const int G = a.n_q_heads / a.n_kv_heads;
+  const int G = __builtin_amdgcn_readfirstlane(small_div(a.n_q_heads, a.n_kv_heads));
   // Folded heads (fold_group > 0): the caller's model has two kv heads of 64 values; their rows
   // stand side by side in a slab row, so the pair is streamed as ONE 128-wide kv head serving all
   // q heads.  q head h belongs to kv head h / fold_group: its query is zero outside that half of
@@ -247,7 +247,7 @@ void decode_mfma_kernel(DecodeArgs a) {
     seq = (int)(seq64 < 0 ? 0 : (seq64 > a.kv.table_cols ? a.kv.table_cols : seq64));
   }
   // the row's pieces are equal among themselves (a piece past the end is empty)
-  int chunk = (seq + n_parts - 1) / n_parts;
+  int chunk = a.balance_target > 0 ? small_div(seq + n_parts - 1, n_parts) : (seq + n_parts - 1) / n_parts;  // (flat grid: seq <= 2^20)
   chunk = (chunk + kTile - 1) / kTile * kTile;
   const int start = split * chunk;
   const int end = (split == n_parts - 1) ? seq : min(seq, start + chunk);
