@@ -508,6 +508,12 @@ void decode_mfma_kernel(DecodeArgs a) {
     }
   }
   if (trace != nullptr && lane == 0) trace[2] = wall_clock64();
+#ifdef BSGL_CUT_AFTER_STREAM
+  // timing experiment (tools/phase_cut.sh; results are wrong): leave after the last tile.  The
+  // never-true store keeps the streaming loop alive.
+  if (o_acc[0][0][0] == 12345.f) a.ws_o[0] = l_run[0];
+  return;
+#endif
   // ---- finish: sum l over the lane groups, normalise, write ---------------------------
   const int64_t n_rh = (int64_t)a.rows * a.n_q_heads;
   constexpr int kOPad = D + 4;
@@ -571,6 +577,9 @@ void decode_mfma_kernel(DecodeArgs a) {
     return;
   }
   // ---- ticket: the last workgroup of this (row, head group) merges all splits ----------
+#ifdef BSGL_CUT_AFTER_PARTIALS
+  return;  // timing experiment (tools/phase_cut.sh; results are wrong): no ticket, no merge
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every partial byte of this wave has left
   uint32_t* counter = a.counters + (int64_t)row * n_hg + hg;
   uint32_t ticket = 0;
