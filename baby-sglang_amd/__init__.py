@@ -13,6 +13,7 @@ from .forward_batch import SimplifiedForwardBatch
 from .memory_pool import BaseTokenToKVPool, MHATokenToKVPool, ReqToTokenPool
 from .qwen2_hip import BabyQwen2ForCausalLM
 from .tp_runtime import (
+    LocalGroup,
     TPLayout,
     init_tp,
     split_tp_groups,
@@ -31,6 +32,7 @@ __all__ = [
     "BaseTokenToKVPool",
     "MHATokenToKVPool",
     "ReqToTokenPool",
+    "LocalGroup",
     "TPLayout",
     "init_tp",
     "split_tp_groups",

@@ -51,6 +51,7 @@ SIGNATURES = {
     "bsgl_last_error": (ctypes.c_char_p, []),
     "bsgl_debug_decode_trace": (None, [_vp]),
     "bsgl_debug_prefill_profile": (None, [_vp]),
+    "bsgl_debug_set_knob": (ctypes.c_int, [ctypes.c_char_p, _i32, ctypes.POINTER(ctypes.c_int32)]),
     "bsgl_kv_scatter": (
         ctypes.c_int,
         [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp],
@@ -117,6 +118,15 @@ def _check(rc: int, what: str) -> None:
     if rc == BSGL_ERR_BAD_ARG:
         raise ValueError(f"{what}: {msg}")
     raise RuntimeError(f"{what} failed ({rc}): {msg}")
+
+
+def set_knob(name: str, value: int) -> int:
+    """Replace one of the library's tuning knobs (named like its environment variable, e.g.
+    ``BSGL_MFMA_WAVES``); returns the value it had.  The library reads the environment once per
+    process, so this is how a test or a tuning script changes a knob afterwards."""
+    prev = ctypes.c_int32(0)
+    _check(lib.bsgl_debug_set_knob(name.encode(), int(value), ctypes.byref(prev)), "bsgl_debug_set_knob")
+    return int(prev.value)
 
 
 def _dtype_code(t: torch.Tensor) -> int:

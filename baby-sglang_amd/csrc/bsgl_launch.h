@@ -11,6 +11,32 @@ namespace bsgl {
 
 enum DType : int32_t { kBF16 = 0, kF16 = 1, kF32 = 2 };
 
+// Tuning knobs.  Each is read from the environment variable of its name ONCE per process (the
+// first time any knob is asked for; thread safe) and kept as an int; bsgl_debug_set_knob replaces a
+// value later.  No entry point calls getenv on its per-call path.
+enum Knob : int {
+  kKnobNoFold,          // BSGL_NO_FOLD: never stream two kv heads of 64 values as one of 128
+  kKnobNoFusedKV,       // BSGL_NO_FUSED_KV: the decode step's KV write is always its own launch
+  kKnobNoFusedMerge,    // BSGL_NO_FUSED_MERGE: split partials are merged by the merge kernel
+  kKnobDecodeBalance,   // BSGL_DECODE_BALANCE: length-balanced pieces (default 1)
+  kKnobDecodeTarget,    // BSGL_DECODE_TARGET: pieces wanted per request (0 = heuristic)
+  kKnobFoldPieces,      // BSGL_FOLD_PIECES: most pieces per request with folded heads (default 8)
+  kKnobDecodeTargetWgs, // BSGL_DECODE_TARGET_WGS: workgroups a decode launch aims for (default 1024)
+  kKnobDecodeMinChunk,  // BSGL_DECODE_MIN_CHUNK: shortest split of the longest possible request (default 128)
+  kKnobPrefillBlk,      // BSGL_PREFILL_BLK: force 16- or 64-position extend blocks
+  kKnobPrefillGroup,    // BSGL_PREFILL_GROUP: force the blocks per group of the extend launch order
+  kKnobMfmaNT,          // BSGL_MFMA_NT: non-temporal K/V requests in the decode kernel (default 1)
+  kKnobMfmaStages,      // BSGL_MFMA_STAGES: ring depth of the decode kernel (default 2)
+  kKnobMfmaHPT,         // BSGL_MFMA_HPT: kv heads per decode workgroup (default 1)
+  kKnobMfmaWaves,       // BSGL_MFMA_WAVES: force the waves that share a decode piece (0 = heuristic)
+  kKnobPrefillRT,       // BSGL_PREFILL_RT: q heads per workgroup of the 16x16x32 extend kernel (0 = heuristic)
+  kKnobPrefill16,       // BSGL_PREFILL_16: keep the 16x16x32 extend kernel where the 32x32x16 form applies
+  kKnobPrefillLdsPad,   // BSGL_PREFILL_LDS_PAD: extra LDS bytes per extend workgroup (lowers occupancy)
+  kKnobDecodeSteal,     // BSGL_DECODE_STEAL: reserved
+  kKnobCount
+};
+int knob(Knob k);
+
 inline int dtype_bytes(int32_t dt) { return dt == kF32 ? 4 : 2; }
 
 struct PagedKV {

@@ -3,10 +3,12 @@
 // No entry point allocates, synchronises or reads device memory.
 #include "../../include/bsgl_attn.h"
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "bsgl_launch.h"
 
@@ -31,6 +33,35 @@ int hip_fail(const char* what, hipError_t e) {
 namespace bsgl {
 // error reporting for the other translation units of the C surface (comm.hip)
 int set_error(int code, const char* msg) { return fail(code, "%s", msg); }
+
+namespace {
+struct KnobDef {
+  const char* name;
+  int dflt;
+};
+// (same order as enum Knob)
+constexpr KnobDef kKnobDefs[kKnobCount] = {
+    {"BSGL_NO_FOLD", 0},          {"BSGL_NO_FUSED_KV", 0},         {"BSGL_NO_FUSED_MERGE", 0},
+    {"BSGL_DECODE_BALANCE", 1},   {"BSGL_DECODE_TARGET", 0},       {"BSGL_FOLD_PIECES", 8},
+    {"BSGL_DECODE_TARGET_WGS", 1024}, {"BSGL_DECODE_MIN_CHUNK", 128}, {"BSGL_PREFILL_BLK", 0},
+    {"BSGL_PREFILL_GROUP", 0},    {"BSGL_MFMA_NT", 1},             {"BSGL_MFMA_STAGES", 2},
+    {"BSGL_MFMA_HPT", 1},         {"BSGL_MFMA_WAVES", 0},          {"BSGL_PREFILL_RT", 0},
+    {"BSGL_PREFILL_16", 0},       {"BSGL_PREFILL_LDS_PAD", 0},     {"BSGL_DECODE_STEAL", 0},
+};
+std::atomic<int> g_knobs[kKnobCount];
+std::once_flag g_knobs_once;
+void load_knobs() {
+  for (int i = 0; i < kKnobCount; ++i) {
+    const char* s = getenv(kKnobDefs[i].name);
+    g_knobs[i].store((s == nullptr || *s == '\0') ? kKnobDefs[i].dflt : atoi(s), std::memory_order_relaxed);
+  }
+}
+}  // namespace
+
+int knob(Knob k) {
+  std::call_once(g_knobs_once, load_knobs);
+  return g_knobs[k].load(std::memory_order_relaxed);
+}
 }  // namespace bsgl
 
 namespace {
@@ -45,11 +76,6 @@ int check_dtype(int32_t dtype) {
   return BSGL_OK;
 }
 
-int env_int(const char* name, int dflt) {
-  const char* s = getenv(name);
-  if (s == nullptr || *s == '\0') return dflt;
-  return atoi(s);
-}
 
 // shared validation of the paged-KV description and the q/out rows
 int check_paged(const void* out, int64_t out_row_stride, const void* q, int64_t q_row_stride,
@@ -94,7 +120,7 @@ int run_decode(bsgl::DecodeArgs& a, int32_t variant, uint32_t* counters, hipStre
   bsgl::DecodeArgs folded = a;
   bool can_fold = false;
   if (a.head_dim == 64 && a.n_kv_heads == 2 && a.n_q_heads % 2 == 0 && a.n_q_heads <= 16 &&
-      (counters != nullptr || bsgl::decode_direct_out(a)) && env_int("BSGL_NO_FOLD", 0) == 0) {
+      (counters != nullptr || bsgl::decode_direct_out(a)) && bsgl::knob(bsgl::kKnobNoFold) == 0) {
     folded.fold_group = a.n_q_heads / 2;
     folded.n_kv_heads = 1;
     folded.head_dim = 128;
@@ -118,7 +144,7 @@ int run_decode(bsgl::DecodeArgs& a, int32_t variant, uint32_t* counters, hipStre
     const int eb = bsgl::dtype_bytes(a.dtype);
     const bool rows_ok = (((uintptr_t)a.k_new | (uintptr_t)a.v_new) % 256 == 0) &&
                          (a.k_new_stride * eb) % 256 == 0 && (a.v_new_stride * eb) % 256 == 0;
-    if (!(use_mfma && may_fuse_kv && rows_ok && env_int("BSGL_NO_FUSED_KV", 0) == 0)) {
+    if (!(use_mfma && may_fuse_kv && rows_ok && bsgl::knob(bsgl::kKnobNoFusedKV) == 0)) {
       bsgl::ScatterArgs sc;
       sc.k_slab = const_cast<void*>(a.kv.k_slab);
       sc.v_slab = const_cast<void*>(a.kv.v_slab);
@@ -140,13 +166,13 @@ int run_decode(bsgl::DecodeArgs& a, int32_t variant, uint32_t* counters, hipStre
   // one ticket per (row, kv head): fall back to the merge kernel when they do not fit
   const bool tickets_fit = (size_t)a.rows * (size_t)a.n_kv_heads * 4 <= kCounterBytes &&
                            (size_t)a.n_splits * a.rows * a.n_q_heads * a.head_dim * 4 < (1ull << 31);
-  a.counters = (use_mfma && tickets_fit && (a.fold_group > 0 || env_int("BSGL_NO_FUSED_MERGE", 0) == 0)) ? counters : nullptr;
+  a.counters = (use_mfma && tickets_fit && (a.fold_group > 0 || bsgl::knob(bsgl::kKnobNoFusedMerge) == 0)) ? counters : nullptr;
   if (a.fold_group > 0 && a.counters == nullptr && !bsgl::decode_direct_out(a))
     return fail(BSGL_ERR_UNSUPPORTED, "folded kv heads need the in-kernel merge (batch too large for the ticket area)");
   // length-balanced pieces: needs the in-kernel merge (a row's piece count varies) and a
   // batch small enough for every workgroup to scan its seq_lens
   a.balance_target = 0;
-  if (a.counters != nullptr && a.n_splits > 1 && a.rows <= 1024 && a.kv.table_cols <= (1 << 20) && !uniform_splits && env_int("BSGL_DECODE_BALANCE", 1) != 0)
+  if (a.counters != nullptr && a.n_splits > 1 && a.rows <= 1024 && a.kv.table_cols <= (1 << 20) && !uniform_splits && bsgl::knob(bsgl::kKnobDecodeBalance) != 0)
     a.balance_target = (a.n_splits + 1) / 2;
   if (a.balance_target > 0) {
     // Small batches get many splits, but pieces much shorter than 256 tokens cost more in the merge
@@ -155,14 +181,14 @@ int run_decode(bsgl::DecodeArgs& a, int32_t variant, uint32_t* counters, hipStre
     // requests: 8 pieces against 16 is 7 - 15 % faster for 4 - 32 requests, 4 % slower for 1 - 2.)
     const int64_t cap = a.kv.table_cols / 512 > 4 ? a.kv.table_cols / 512 : 4;
     if (a.balance_target > cap) a.balance_target = (int32_t)cap;
-    const int t = env_int("BSGL_DECODE_TARGET", 0);  // tuning override: pieces wanted per request
+    const int t = bsgl::knob(bsgl::kKnobDecodeTarget);  // tuning override: pieces wanted per request
     if (t > 0 && t <= a.n_splits) a.balance_target = t;
   }
   // (folded heads: the workgroup that merges a request reads the partial rows of ALL its q heads,
   // 14 for Qwen2.5-0.5B: more than 8 pieces per request cost more in that merge than they gain)
   // -- and with half as many kv heads to cut, up to n_splits pieces are wanted below that
   if (a.fold_group > 0 && a.balance_target > 0) {
-    const int cap = env_int("BSGL_FOLD_PIECES", 8);
+    const int cap = bsgl::knob(bsgl::kKnobFoldPieces);
     a.balance_target = a.n_splits < cap ? a.n_splits : cap;
   }
   const hipError_t e = use_mfma ? bsgl::launch_decode_mfma(a, stream) : bsgl::launch_decode_valu(a, stream);
@@ -182,6 +208,19 @@ static uint64_t* g_prefill_prof = nullptr;
 void bsgl_debug_prefill_profile(void* device_buf) { g_prefill_prof = (uint64_t*)device_buf; }
 
 const char* bsgl_last_error(void) { return g_err; }
+
+int bsgl_debug_set_knob(const char* name, int32_t value, int32_t* previous) {
+  if (name == nullptr) return fail(BSGL_ERR_BAD_ARG, "null knob name");
+  for (int i = 0; i < bsgl::kKnobCount; ++i) {
+    if (strcmp(name, bsgl::kKnobDefs[i].name) == 0) {
+      const int old = bsgl::knob((bsgl::Knob)i);  // (loads the environment's values first)
+      if (previous != nullptr) *previous = old;
+      bsgl::g_knobs[i].store(value, std::memory_order_relaxed);
+      return BSGL_OK;
+    }
+  }
+  return fail(BSGL_ERR_BAD_ARG, "unknown knob %s", name);
+}
 
 int bsgl_kv_scatter(void* k_slab, void* v_slab, int64_t slab_row_stride, int64_t n_slots,
                     const int32_t* loc, const void* k_new, const void* v_new,
@@ -228,8 +267,8 @@ static int32_t decode_splits(int32_t batch, int32_t n_kv_heads, int32_t max_cont
   if (n_kv_heads < 1) n_kv_heads = 1;
   // enough workgroups to put several on each of the 256 CUs, but no split
   // shorter than min_chunk tokens of the longest possible request
-  const int target_wgs = env_int("BSGL_DECODE_TARGET_WGS", 1024);
-  const int min_chunk = env_int("BSGL_DECODE_MIN_CHUNK", 128);
+  const int target_wgs = bsgl::knob(bsgl::kKnobDecodeTargetWgs);
+  const int min_chunk = bsgl::knob(bsgl::kKnobDecodeMinChunk);
   // one workgroup per (request, kv head, split)
   const int64_t per_split = (int64_t)batch * n_kv_heads;
   int splits = (int)((target_wgs + per_split - 1) / per_split);
@@ -395,7 +434,7 @@ int bsgl_paged_prefill(void* out, int64_t out_row_stride, const void* q, int64_t
   const int64_t short_below = n_kv_heads > 0 && n_q_heads / n_kv_heads >= 2 ? 44 : 24;
   pa.blk_rows = (int64_t)total_q_tokens >= short_below * batch ? 64 : 16;
   {
-    const int forced = env_int("BSGL_PREFILL_BLK", 0);  // tuning override
+    const int forced = bsgl::knob(bsgl::kKnobPrefillBlk);  // tuning override
     if (forced == 16 || forced == 64) pa.blk_rows = forced;
   }
   ex.blk_rows = pa.blk_rows;
@@ -408,7 +447,7 @@ int bsgl_paged_prefill(void* out, int64_t out_row_stride, const void* q, int64_t
     const int64_t mean_blocks = ((int64_t)total_q_tokens + per - 1) / per;
     int grp = 1;
     while (grp < 8 && grp < mean_blocks) grp *= 2;
-    const int forced = env_int("BSGL_PREFILL_GROUP", 0);  // tuning override
+    const int forced = bsgl::knob(bsgl::kKnobPrefillGroup);  // tuning override
     pa.grp_blocks = forced > 0 ? forced : grp;
   }
   ex.grp_blocks = pa.grp_blocks;
@@ -429,7 +468,7 @@ int bsgl_paged_prefill(void* out, int64_t out_row_stride, const void* q, int64_t
   if (kind != BSGL_DECODE_AUTO && kind != BSGL_DECODE_VALU && kind != BSGL_DECODE_MFMA)
     return fail(BSGL_ERR_BAD_ARG, "unknown variant %d", variant);
   // two kv heads of 64 values (Qwen2.5-0.5B): streamed as one 128-wide kv head (see run_decode)
-  if (head_dim == 64 && n_kv_heads == 2 && n_q_heads % 2 == 0 && n_q_heads <= 16 && env_int("BSGL_NO_FOLD", 0) == 0) {
+  if (head_dim == 64 && n_kv_heads == 2 && n_q_heads % 2 == 0 && n_q_heads <= 16 && bsgl::knob(bsgl::kKnobNoFold) == 0) {
     bsgl::PrefillArgs folded = pa;
     folded.fold_group = n_q_heads / 2;
     folded.n_kv_heads = 1;

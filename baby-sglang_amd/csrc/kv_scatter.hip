@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256) void kv_scatter_kernel(ScatterArgs a) {
 }
 
 // exclusive running sums of extended_lens and of the block groups of each request,
-// ceil(ceil(extended_lens / blk_rows) / grp_blocks)  (negative lengths count as 0)
+// ceil(ceil(extended_lens / blk_rows) / grp_blocks)  (negative lengths count as 0, lengths above
+// the number of q rows as that number)
 __global__ void prefill_cu_kernel(ExpandArgs a) {
   __shared__ int64_t s_ext[256], s_blk[256];
   const int tid = threadIdx.x;
@@ -42,7 +43,7 @@ __global__ void prefill_cu_kernel(ExpandArgs a) {
   const int64_t gb = a.grp_blocks > 0 ? a.grp_blocks : 1;
   int64_t sum = 0, blocks = 0;
   for (int i = lo; i < hi; ++i) {
-    const int64_t e = max((int64_t)0, a.extended_lens[i]);
+    const int64_t e = min(max((int64_t)0, a.extended_lens[i]), (int64_t)a.total_q_tokens);  // (bounded: the sums cannot overflow)
     sum += e;
     blocks += ((e + br - 1) / br + gb - 1) / gb;
   }
@@ -64,7 +65,7 @@ __global__ void prefill_cu_kernel(ExpandArgs a) {
   __syncthreads();
   int64_t run = s_ext[tid], brun = s_blk[tid];
   for (int i = lo; i < hi; ++i) {
-    const int64_t e = max((int64_t)0, a.extended_lens[i]);
+    const int64_t e = min(max((int64_t)0, a.extended_lens[i]), (int64_t)a.total_q_tokens);  // (bounded: the sums cannot overflow)
     a.cu_ext[i] = run;
     if (a.cu_blk != nullptr) a.cu_blk[i] = brun;
     run += e;

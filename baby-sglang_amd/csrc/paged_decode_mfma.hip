@@ -717,17 +717,12 @@ void decode_mfma_kernel(DecodeArgs a) {
 
 uint64_t* g_trace = nullptr;
 
-int env_int(const char* name, int dflt) {
-  const char* s = getenv(name);
-  return (s == nullptr || *s == '\0') ? dflt : atoi(s);
-}
-
 template <typename Tag, int HPT, int NSTAGE>
 hipError_t launch_inst(const DecodeArgs& a, hipStream_t stream) {
   dim3 grid(a.rows, a.n_kv_heads / HPT, a.n_splits);
   // flat list of length-balanced pieces: at most rows * target + rows of them
   if (a.balance_target > 0) grid = dim3((unsigned)((int64_t)a.rows * (a.balance_target + 1) * (a.n_kv_heads / HPT)), 1, 1);
-  if (env_int("BSGL_MFMA_NT", 1))
+  if (knob(kKnobMfmaNT))
     hipLaunchKernelGGL((decode_mfma_kernel<Tag, HPT, NSTAGE, true>), grid, dim3(64), 0, stream, a);
   else
     hipLaunchKernelGGL((decode_mfma_kernel<Tag, HPT, NSTAGE, false>), grid, dim3(64), 0, stream, a);
@@ -736,9 +731,9 @@ hipError_t launch_inst(const DecodeArgs& a, hipStream_t stream) {
 
 template <typename Tag>
 hipError_t launch_tag(const DecodeArgs& a, hipStream_t stream) {
-  // tuning knobs (read per call; defaults are the measured best)
-  const int stages = env_int("BSGL_MFMA_STAGES", 2);
-  const int hpt = (a.n_kv_heads % 2 == 0) ? env_int("BSGL_MFMA_HPT", 1) : 1;
+  // tuning knobs (defaults are the measured best)
+  const int stages = knob(kKnobMfmaStages);
+  const int hpt = (a.n_kv_heads % 2 == 0) ? knob(kKnobMfmaHPT) : 1;
   if (hpt == 2) {
     if (stages == 3) return launch_inst<Tag, 2, 3>(a, stream);
     return launch_inst<Tag, 2, 2>(a, stream);
@@ -750,10 +745,10 @@ hipError_t launch_tag(const DecodeArgs& a, hipStream_t stream) {
   const int64_t n_pieces = (int64_t)a.rows * a.n_kv_heads * (a.balance_target > 0 ? a.balance_target : a.n_splits);
   int waves = n_pieces > 512 ? 1 : n_pieces > 256 ? 2 : 4;
   {
-    const int forced = env_int("BSGL_MFMA_WAVES", 0);  // tuning override
+    const int forced = knob(kKnobMfmaWaves);  // tuning override
     if (forced == 1 || forced == 2 || forced == 4) waves = forced;
   }
-  if (waves > 1 && env_int("BSGL_MFMA_NT", 1)) {
+  if (waves > 1 && knob(kKnobMfmaNT)) {
     dim3 grid(a.rows, a.n_kv_heads, a.n_splits);
     if (a.balance_target > 0) grid = dim3((unsigned)((int64_t)a.rows * (a.balance_target + 1) * a.n_kv_heads), 1, 1);
     if (waves == 2)

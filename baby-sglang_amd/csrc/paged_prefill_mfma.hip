@@ -114,18 +114,21 @@ void prefill_mfma_kernel(PrefillArgs a) {
     i_req += __popcll(__ballot(le));
   }
   i_req = min(i_req, a.batch - 1);
-  const int64_t ext_raw = a.extended_lens[i_req];
-  const int n_blocks = (int)(((ext_raw < 0 ? 0 : ext_raw) + 16 * WAVES - 1) / (16 * WAVES));
+  // rows this request may own: never past the last row of q / out, whatever extended_lens says
+  // (inconsistent metadata gives wrong numbers, not an access outside the tensors)
+  const int64_t q_first = a.cu_ext[i_req];
+  const int64_t ext_raw = max((int64_t)0, min(a.extended_lens[i_req], (int64_t)a.total_q_tokens - q_first));
+  const int n_blocks = (int)((ext_raw + 16 * WAVES - 1) / (16 * WAVES));
   const int bg0 = (int)(pg - a.cu_blk[i_req]) * a.grp_blocks;  // first block of the group
   const int nb = min(a.grp_blocks, n_blocks - bg0);            // blocks in it (>= 1)
   if (within / n_z >= nb) return;
   // a request's last blocks see the most tokens: they go first
   const int q0_wg = (bg0 + nb - 1 - within / n_z) * (16 * WAVES);
-  const int64_t ext64 = a.extended_lens[i_req];
+  const int64_t ext64 = ext_raw;
   const int rows_wg = (int)min((int64_t)(16 * WAVES), ext64 - q0_wg);  // >= 1: the block exists
   const int q0 = q0_wg + 16 * wave;
   const int n_rows = max(0, min(16, rows_wg - 16 * wave));  // 0: this wave only helps to load
-  const int64_t q_row0 = a.cu_ext[i_req] + q0;
+  const int64_t q_row0 = q_first + q0;
   int64_t req = a.req_idx[i_req];
   req = req < 0 ? 0 : (req >= a.kv.table_rows ? a.kv.table_rows - 1 : req);
   const int64_t seq64 = a.seq_lens[i_req];
@@ -420,10 +423,9 @@ hipError_t launch_tag(const PrefillArgs& a, hipStream_t stream) {
   // TFLOP/s, 1 head (three waves) 358, 2 heads (two waves) 388, odd groups included.
   const int g = a.n_q_heads / a.n_kv_heads;
   int rt = g == 1 ? 1 : 2;
-  const char* e = getenv("BSGL_PREFILL_RT");  // tuning override
-  if (e != nullptr && *e != '\0') rt = atoi(e);
-  const char* e16 = getenv("BSGL_PREFILL_16");  // tuning override: keep this kernel where the 32x32x16 form applies
-  if (rt == 2 && prefill_mfma32_supported(a) && !(e16 != nullptr && *e16 == '1')) return launch_prefill_mfma32(a, stream);
+  if (knob(kKnobPrefillRT) > 0) rt = knob(kKnobPrefillRT);  // tuning override
+  // (kKnobPrefill16: tuning override, keeps this kernel where the 32x32x16 form applies)
+  if (rt == 2 && prefill_mfma32_supported(a) && knob(kKnobPrefill16) != 1) return launch_prefill_mfma32(a, stream);
   switch (rt) {
     case 1: return launch_rt<Tag, 1>(a, stream);
     case 2: return launch_rt<Tag, 2>(a, stream);

@@ -112,8 +112,11 @@ void prefill_mfma32_kernel(PrefillArgs a) {
     i_req += __popcll(__ballot(le));
   }
   i_req = min(i_req, a.batch - 1);
-  const int64_t ext_raw = a.extended_lens[i_req];
-  const int n_blocks = (int)(((ext_raw < 0 ? 0 : ext_raw) + ROWS - 1) / ROWS);
+  // rows this request may own: never past the last row of q / out, whatever extended_lens says
+  // (inconsistent metadata gives wrong numbers, not an access outside the tensors)
+  const int64_t q_first = a.cu_ext[i_req];
+  const int64_t ext_raw = max((int64_t)0, min(a.extended_lens[i_req], (int64_t)a.total_q_tokens - q_first));
+  const int n_blocks = (int)((ext_raw + ROWS - 1) / ROWS);
   const int bg0 = (int)(pg - a.cu_blk[i_req]) * a.grp_blocks;
   const int nb = min(a.grp_blocks, n_blocks - bg0);
   const int bi = within / n_z;  // block of the group, counted from the request's end (last blocks first)
@@ -135,7 +138,7 @@ void prefill_mfma32_kernel(PrefillArgs a) {
   const int n_heads = PW == 32 ? (head_ok ? 1 : 0) : max(0, min(CH, n_rt - hw));  // q heads this wave really has
   const int n_rows = n_heads > 0 ? max(0, min(PW, rows_blk - pos_off)) : 0;       // positions it really has
   const bool col_ok = pos < n_rows && hsub < n_heads;
-  const int64_t q_row0 = a.cu_ext[i_req] + q0;
+  const int64_t q_row0 = q_first + q0;
   int64_t req = a.req_idx[i_req];
   req = req < 0 ? 0 : (req >= a.kv.table_rows ? a.kv.table_rows - 1 : req);
   const int64_t seq64 = a.seq_lens[i_req];
@@ -473,8 +476,7 @@ hipError_t launch_prefill_mfma32(const PrefillArgs& a, hipStream_t stream) {
   const int64_t n_wg = 8 * local_groups * a.grp_blocks * n_z;
   if (n_wg > 0x7fffffffll) return hipErrorInvalidValue;
   dim3 grid((unsigned)n_wg, 1, 1);
-  const char* pad_e = getenv("BSGL_PREFILL_LDS_PAD");  // tuning aid: extra LDS per workgroup, to lower the occupancy
-  const unsigned pad = pad_e != nullptr ? (unsigned)atoi(pad_e) : 0u;
+  const unsigned pad = (unsigned)max(0, knob(kKnobPrefillLdsPad));  // tuning aid: extra LDS per workgroup, to lower the occupancy
   if (a.blk_rows == 64) {
     if (a.dtype == kBF16)
       hipLaunchKernelGGL((prefill_mfma32_kernel<bf16_tag, 32>), grid, dim3(256), pad, stream, a);

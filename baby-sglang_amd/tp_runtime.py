@@ -24,8 +24,9 @@ collectives per layer and no ring of small steps.
 from __future__ import annotations
 
 import os
+import threading
 from dataclasses import dataclass
-from typing import Callable, Optional, Tuple
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -55,6 +56,101 @@ def init_tp(backend: Optional[str] = None) -> Tuple[int, int, object]:
     return rank, world_size, tp_group
 
 
+class LocalGroup:
+    """A tensor-parallel group whose ranks are THREADS of one process, all on one device (one
+    GPU, or the CPU) -- a rehearsal of the multi-GPU path where only one GPU is at hand: every
+    rank runs the real kernels on its own shard (own pool, own page table), and the four
+    wrappers and the attention exchange below move tensors between the threads instead of over
+    RCCL.  Pass it wherever a ``torch.distributed`` group goes.  Every rank's thread calls
+    ``bind(rank)`` first and then makes the same sequence of collective calls; all ranks must
+    issue their GPU work on ONE stream (the device's default stream is shared by threads), so
+    that a rank reads a peer's tensor behind the launch that produced it.  ``run(fn)`` starts
+    one thread per rank and re-raises the first failure."""
+
+    def __init__(self, world: int, _parent: Optional["LocalGroup"] = None, _members: Optional[Sequence[int]] = None):
+        if world < 1:
+            raise ValueError("a group needs at least one rank")
+        self.world = world
+        self._parent = _parent
+        self._members = list(_members) if _members is not None else list(range(world))
+        self._barrier = threading.Barrier(world)
+        self._slots: List[object] = [None] * world
+        self._tls = threading.local() if _parent is None else None
+        self._subgroups = {}
+        self._lock = threading.Lock()
+
+    # -- rank bookkeeping
+    def bind(self, rank: int) -> None:
+        if self._parent is not None:
+            raise ValueError("bind the top-level group; sub-groups follow it")
+        if not 0 <= rank < self.world:
+            raise ValueError(f"rank {rank} outside a group of {self.world}")
+        self._tls.rank = rank
+
+    def rank(self) -> int:
+        if self._parent is None:
+            r = getattr(self._tls, "rank", None)
+            if r is None:
+                raise RuntimeError("LocalGroup.bind(rank) was not called on this thread")
+            return r
+        return self._members.index(self._parent.rank())
+
+    def subgroup(self, members: Sequence[int]) -> "LocalGroup":
+        """The group of the given ranks of this group (every member gets the same object)."""
+        key = tuple(members)
+        with self._lock:
+            if key not in self._subgroups:
+                self._subgroups[key] = LocalGroup(len(key), _parent=self, _members=key)
+            return self._subgroups[key]
+
+    # -- the one primitive: everybody's value, in rank order, with `fn` applied between two barriers
+    def exchange(self, value, fn: Callable):
+        """``fn(values of all ranks, in rank order)``, evaluated on every rank while all the
+        values are alive and unchanged; ranks leave together (so a rank may overwrite its
+        value in place afterwards)."""
+        self._slots[self.rank()] = value
+        self._barrier.wait(timeout=120)
+        try:
+            result = fn(list(self._slots))
+        except BaseException:
+            self._barrier.abort()
+            raise
+        self._barrier.wait(timeout=120)
+        return result
+
+    def abort(self) -> None:
+        self._barrier.abort()
+        for g in list(self._subgroups.values()):
+            g.abort()
+
+    def run(self, fn: Callable[[int], object]) -> list:
+        """``fn(rank)`` on one thread per rank; returns the results in rank order."""
+        results: List[object] = [None] * self.world
+        errors: List[BaseException] = []
+
+        def body(rank):
+            try:
+                self.bind(rank)
+                results[rank] = fn(rank)
+            except BaseException as exc:  # noqa: BLE001  (handed to the caller below)
+                errors.append(exc)
+                self.abort()
+
+        threads = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(self.world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        first = next((e for e in errors if not isinstance(e, threading.BrokenBarrierError)), errors[0] if errors else None)
+        if first is not None:
+            raise first
+        return results
+
+
+def _local(tp_group) -> bool:
+    return isinstance(tp_group, LocalGroup)
+
+
 _REPLICA_GROUPS = {}
 
 
@@ -63,6 +159,14 @@ def split_tp_groups(tp_size: int, world_group=None):
     consecutive ranks (replicas that serve different requests: requests are independent, so
     nothing is exchanged between replicas).  Returns ``(tp_group, tp_rank, replica, n_replicas)``.
     Every rank creates every group, in the same order, as ``new_group`` demands."""
+    if _local(world_group):
+        world, rank = world_group.world, world_group.rank()
+        if tp_size < 1 or world % tp_size:
+            raise ValueError(f"tp_size {tp_size} does not divide the world of {world}")
+        if tp_size == world:
+            return world_group, rank, 0, 1
+        g0 = rank // tp_size * tp_size
+        return world_group.subgroup(range(g0, g0 + tp_size)), rank % tp_size, rank // tp_size, world // tp_size
     if not dist.is_initialized():
         if tp_size != 1:
             raise ValueError("a tensor-parallel group of more than one rank needs an initialised process group")
@@ -113,6 +217,8 @@ def _capi(x: torch.Tensor, tp_group) -> bool:
 
 
 def _world(tp_group) -> int:
+    if _local(tp_group):
+        return tp_group.world
     if not dist.is_initialized():
         return 1
     return dist.get_world_size(group=tp_group)
@@ -120,6 +226,11 @@ def _world(tp_group) -> int:
 
 def tp_all_reduce_sum(x: torch.Tensor, tp_group) -> torch.Tensor:
     if _world(tp_group) == 1:
+        return x
+    if _local(tp_group):
+        # (summed in rank order on every rank: all ranks get the same bits)
+        total = tp_group.exchange(x, lambda xs: torch.stack([t.to(x.device) for t in xs]).sum(dim=0).to(x.dtype))
+        x.copy_(total)
         return x
     if _capi(x, tp_group) and x.is_contiguous():
         from . import _hip
@@ -133,6 +244,8 @@ def tp_all_gather(x: torch.Tensor, tp_group) -> torch.Tensor:
     world = _world(tp_group)
     if world == 1:
         return x
+    if _local(tp_group):
+        return tp_group.exchange(x, lambda xs: torch.cat([t.to(x.device) for t in xs], dim=0))
     if _capi(x, tp_group):
         from . import _hip
 
@@ -150,6 +263,9 @@ def tp_all_gather(x: torch.Tensor, tp_group) -> torch.Tensor:
 
 def tp_broadcast(x: torch.Tensor, src: int, tp_group) -> torch.Tensor:
     if _world(tp_group) == 1:
+        return x
+    if _local(tp_group):
+        x.copy_(tp_group.exchange(x, lambda xs: xs[src].clone()))
         return x
     dist.broadcast(x, src=src, group=tp_group)
     return x
@@ -241,10 +357,14 @@ def seq_slice_group(layout: TPLayout, tp_group):
     """The process group of the ranks that hold the same kv heads as this rank (its
     sequence-slice peers).  Created once per (world, tp_seq) -- by every rank, for every kv
     shard, in the same order, as ``new_group`` demands."""
-    if layout.tp_seq == 1 or not dist.is_initialized():
+    if layout.tp_seq == 1:
         return None
     if layout.tp_kv == 1:
         return tp_group
+    if _local(tp_group):
+        return tp_group.subgroup(range(layout.kv_rank * layout.tp_seq, (layout.kv_rank + 1) * layout.tp_seq))
+    if not dist.is_initialized():
+        return None
     key = (layout.world, layout.tp_seq)
     if key not in _SEQ_GROUPS:
         groups = [dist.new_group(list(range(k * layout.tp_seq, (k + 1) * layout.tp_seq))) for k in range(layout.tp_kv)]
@@ -254,6 +374,9 @@ def seq_slice_group(layout: TPLayout, tp_group):
 
 def tp_all_to_all(x: torch.Tensor, group) -> torch.Tensor:
     """``out[j] = (rank j's x)[this rank's index]`` over dim 0 (one equal piece per rank)."""
+    if _local(group):
+        me = group.rank()
+        return group.exchange(x, lambda xs: torch.stack([t[me] for t in xs]))
     out = torch.empty_like(x)
     if x.is_cuda and dist.get_backend(group) == "gloo":
         # (gloo has no device all-to-all: host staging, rehearsals only)

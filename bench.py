@@ -312,14 +312,11 @@ def cpu_baseline(args, budget_s):
     }
 
 
-def extend_extras(dev, reps=5):
-    """Extend (prefill) attention beside the headline: one layer call of a 7B-shaped chunked
-    prefill (128 requests, 512 new tokens over 1536 cached, Hq=28 / Hkv=4, bf16, random-permutation
-    page table) -- ms per layer call, TFLOP/s with flops = 4 Hq D (ext * prefix + ext (ext + 1) / 2)
-    per request, and the fraction of the dense bf16 MFMA peak (2.5 PFLOP/s)."""
+def extend_problem(dev, batch=128, ext=512, prefix=1536, hq=28, hkv=4, dim=128):
+    """The extend side measurement's inputs (7B shapes by default): `batch` requests, `ext` new
+    tokens each over `prefix` cached ones, bf16, random-permutation page table."""
     import baby_sglang_amd as pkg
 
-    batch, ext, prefix, hq, hkv, dim = 128, 512, 1536, 28, 4, 128
     seq = prefix + ext
     gen = torch.Generator(device=dev).manual_seed(0)
     kv = pkg.MHATokenToKVPool(batch * seq, torch.bfloat16, hkv, dim, 1, str(dev))
@@ -327,15 +324,29 @@ def extend_extras(dev, reps=5):
     r2t = pkg.ReqToTokenPool(batch, seq, str(dev))
     r2t.req_to_token.copy_((torch.randperm(batch * seq, generator=gen, device=dev).to(torch.int32) + 1).view(batch, seq))
     q = torch.randn((batch * ext, hq, dim), generator=gen, device=dev).to(torch.bfloat16)
-    rows = torch.arange(batch, device=dev)
-    seq_t = torch.full((batch,), seq, dtype=torch.int64, device=dev)
-    pre_t = torch.full((batch,), prefix, dtype=torch.int64, device=dev)
     k_slab, v_slab = kv.get_kv_buffer(0)
+    return dict(batch=batch, ext=ext, prefix=prefix, hq=hq, hkv=hkv, dim=dim, kv=kv, r2t=r2t, q=q,
+                k_slab=k_slab, v_slab=v_slab, rows=torch.arange(batch, device=dev),
+                seq=torch.full((batch,), seq, dtype=torch.int64, device=dev),
+                pre=torch.full((batch,), prefix, dtype=torch.int64, device=dev),
+                out=torch.empty((q.shape[0], hq * dim), dtype=torch.bfloat16, device=dev))
+
+
+def extend_extras(dev, reps=5):
+    """Extend (prefill) attention beside the headline: one layer call of a 7B-shaped chunked
+    prefill (128 requests, 512 new tokens over 1536 cached, Hq=28 / Hkv=4, bf16, random-permutation
+    page table) -- ms per layer call, TFLOP/s with flops = 4 Hq D (ext * prefix + ext (ext + 1) / 2)
+    per request, and the fraction of the dense bf16 MFMA peak (2.5 PFLOP/s)."""
+    import baby_sglang_amd as pkg
+
+    p = extend_problem(dev)
+    batch, ext, prefix, hq, dim = p["batch"], p["ext"], p["prefix"], p["hq"], p["dim"]
+    q, out = p["q"], p["out"]
     ws = torch.empty(pkg._hip.prefill_workspace_bytes(batch, q.shape[0], hq, dim), dtype=torch.uint8, device=dev)
-    out = torch.empty((q.shape[0], hq * dim), dtype=torch.bfloat16, device=dev)
 
     def call():
-        pkg._hip.paged_prefill(q, k_slab, v_slab, r2t.req_to_token, rows, seq_t, pre_t, seq_t - pre_t, out=out, workspace=ws)
+        pkg._hip.paged_prefill(q, p["k_slab"], p["v_slab"], p["r2t"].req_to_token, p["rows"], p["seq"], p["pre"],
+                               p["seq"] - p["pre"], out=out, workspace=ws)
 
     call()
     torch.cuda.synchronize()

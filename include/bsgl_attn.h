@@ -77,6 +77,14 @@ void bsgl_debug_decode_trace(void* device_buf);
  * DMA, in the score / softmax half, in the PV half, and its step count. */
 void bsgl_debug_prefill_profile(void* device_buf);
 
+/* Tuning aid with no counterpart in the reference: the library's tuning knobs are read from the
+ * environment variables of their names (BSGL_MFMA_WAVES, BSGL_NO_FUSED_MERGE, ...) once per
+ * process; this call replaces one knob's value afterwards and hands back the value it had
+ * (previous may be NULL).  BSGL_ERR_BAD_ARG for a name the library does not know.  Meant for
+ * tests and tuning scripts: a change while other threads are inside the library is seen by
+ * their calls at an unspecified moment. */
+int bsgl_debug_set_knob(const char* name, int32_t value, int32_t* previous);
+
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char* bsgl_last_error(void);
 

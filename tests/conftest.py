@@ -42,3 +42,19 @@ def gpu():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def knobs():
+    """``knobs(NAME, value)`` sets one of the library's tuning knobs for the test (the library
+    reads the environment only once per process) and puts the old value back afterwards."""
+    from baby_sglang_amd import _hip
+
+    saved = []
+
+    def set_(name, value):
+        saved.append((name, _hip.set_knob(name, value)))
+
+    yield set_
+    for name, old in reversed(saved):
+        _hip.set_knob(name, old)

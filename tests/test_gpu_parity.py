@@ -190,14 +190,14 @@ def test_decode_random_ragged(gpu, dtype, hq, hkv, dim, variant):
 
 @pytest.mark.parametrize("waves", [1, 2, 4])
 @pytest.mark.parametrize("dtype,hq,hkv,dim", [(torch.bfloat16, 12, 2, 128), (torch.float16, 28, 4, 128), (torch.bfloat16, 14, 2, 64)])
-def test_pieces_shared_by_the_waves_of_a_workgroup(gpu, dtype, hq, hkv, dim, waves, monkeypatch):
+def test_pieces_shared_by_the_waves_of_a_workgroup(gpu, dtype, hq, hkv, dim, waves, knobs):
     """Small launches give a piece to two or four waves (tiles in turn, states added up in LDS):
     every width against the oracle, on lengths that leave some waves without a tile (1, 16, 17
     tokens), with a block border inside a piece (600, 1100 tokens in one piece) and with splits;
     output, log-sum-exp and the fused write of the new token."""
     from baby_sglang_amd import _hip
 
-    monkeypatch.setenv("BSGL_MFMA_WAVES", str(waves))
+    knobs("BSGL_MFMA_WAVES", waves)
     seq_lens = [1, 16, 17, 33, 600, 1100, 64, 2047]
     cpu, r2t, kv = random_decode_problem(gpu, dtype, hq, hkv, dim, seq_lens, seed=11 * hq + waves)
     gen = torch.Generator().manual_seed(8)
@@ -268,7 +268,7 @@ def test_two_kv_heads_of_64_on_the_matrix_core_kernel(gpu, dtype, hq):
 
 
 @pytest.mark.parametrize("dtype,hq,hkv", [(torch.bfloat16, 12, 2), (torch.float16, 28, 4), (torch.bfloat16, 6, 1)])
-def test_fused_kv_write_and_merge(gpu, dtype, hq, hkv, monkeypatch):
+def test_fused_kv_write_and_merge(gpu, dtype, hq, hkv, knobs):
     """The decode kernel that stores the new token itself and merges its own
     splits must agree bit for bit with the three-launch form (scatter kernel,
     decode, merge kernel) on output, lse and slab contents -- twice in a row on
@@ -292,7 +292,7 @@ def test_fused_kv_write_and_merge(gpu, dtype, hq, hkv, monkeypatch):
         for fused in (True, False):
             kv.k_buffer[0].copy_(cpu["k_slab"])
             kv.v_buffer[0].copy_(cpu["v_slab"])
-            monkeypatch.setenv("BSGL_NO_FUSED_MERGE", "0" if fused else "1")
+            knobs("BSGL_NO_FUSED_MERGE", 0 if fused else 1)
             k_slab, v_slab = kv.get_kv_buffer(0)
             lse = torch.empty((n_req, hq), dtype=torch.float32, device=gpu)
             out = _hip.paged_decode(q[:n_req], k_slab, v_slab, r2t.req_to_token, rows[:n_req], seq[:n_req],
@@ -340,7 +340,7 @@ def test_length_balanced_splits(gpu, dtype):
 
 
 @pytest.mark.parametrize("length", [1, 15, 16, 777, 2048])
-def test_equal_lengths_take_the_closed_form_of_the_piece_search(gpu, length, monkeypatch):
+def test_equal_lengths_take_the_closed_form_of_the_piece_search(gpu, length, knobs):
     """A batch of at most 64 requests of ONE length finds its pieces in closed form instead of the
     wave-wide search.  Both must cut a request the same way: the first rows of a 65-request batch
     of that length (searched: more than 64 rows) and the same rows as a batch of their own
@@ -349,7 +349,7 @@ def test_equal_lengths_take_the_closed_form_of_the_piece_search(gpu, length, mon
 
     # (one wave per piece whatever the batch: small launches otherwise share a piece among
     # several waves, which changes the order of the sums, not the pieces)
-    monkeypatch.setenv("BSGL_MFMA_WAVES", "1")
+    knobs("BSGL_MFMA_WAVES", 1)
     hq, hkv, dim, dtype = 12, 2, 128, torch.bfloat16
     cpu, r2t, kv = random_decode_problem(gpu, dtype, hq, hkv, dim, [length] * 65, seed=77 + length)
     want = orc.decode_exact(cpu["q"], cpu["k_slab"], cpu["v_slab"], cpu["req_to_token"], cpu["req_pool_indices"], cpu["seq_lens"])
@@ -420,6 +420,30 @@ def test_bad_metadata_never_faults(gpu):
     torch.cuda.synchronize()
     assert float(k_slab[1].float().min()) == 1.0
     assert torch.equal(k_slab[2:], before[2:]) and torch.equal(k_slab[0], before[0])
+
+
+@pytest.mark.parametrize("variant", [2, 1])
+@pytest.mark.parametrize("hq,hkv,n_q", [(12, 2, 70), (12, 2, 9), (4, 4, 70)])
+def test_bad_extend_metadata_never_leaves_q_and_out(gpu, variant, hq, hkv, n_q):
+    """extended_lens that promise more rows than q / out have (one request far too long, the sum
+    too long, a negative one): every extend kernel -- 64- and 16-position blocks, the 32x32x16 and
+    the 16x16x32 forms, the generic rows -- must stay inside the n_q rows it was given.  `out` is
+    the head of a larger buffer whose tail must keep its fill."""
+    from baby_sglang_amd import _hip
+
+    dim, dtype = 128, torch.float16
+    cpu, r2t, kv = random_decode_problem(gpu, dtype, hq, hkv, dim, [300, 200, 150, 90], seed=13)
+    k_slab, v_slab = kv.get_kv_buffer(0)
+    rows, seq = cpu["req_pool_indices"].to(gpu), cpu["seq_lens"].to(gpu)
+    q = torch.randn((n_q, hq, dim), device=gpu).to(dtype)
+    guard_rows = 256
+    for ext, pre in (([40, 500, 30, 20], [0, 0, 0, 0]), ([10**7, 5, 5, 5], [10, 0, 0, 0]), ([30, -4, 10**12, 2], [0, 7, 3, 0])):
+        buf = torch.full((n_q + guard_rows, hq * dim), 7.0, dtype=dtype, device=gpu)
+        out = _hip.paged_prefill(q, k_slab, v_slab, r2t.req_to_token, rows, seq, torch.tensor(pre, device=gpu),
+                                 torch.tensor(ext, device=gpu), variant=variant, out=buf[:n_q])
+        torch.cuda.synchronize()
+        assert out.data_ptr() == buf.data_ptr()
+        assert bool((buf[n_q:] == 7.0).all()), f"rows past the end of out were written (ext {ext})"
 
 
 def test_errors_map_to_python_exceptions(gpu):

@@ -168,3 +168,74 @@ def test_world_of_one_needs_no_process_group():
     assert tp.tp_all_reduce_sum(x, None) is x
     assert tp.tp_all_gather(x, None) is x
     assert tp.tp_broadcast(x, 0, None) is x
+
+
+def _sharded_decode_check(tp, orc, layout, group, n_kv_heads, seq_lens):
+    """One rank's part of a sharded decode on the CPU oracle + the exchange; returns the error
+    against the unsharded result."""
+    hq, dim = 4 * n_kv_heads, 64
+    gen = torch.Generator().manual_seed(0)  # same data on every rank
+    n_slots = sum(seq_lens) + 1
+    k_slab = torch.randn((n_slots, n_kv_heads, dim), generator=gen)
+    v_slab = torch.randn((n_slots, n_kv_heads, dim), generator=gen)
+    q = torch.randn((len(seq_lens), hq, dim), generator=gen)
+    table = torch.zeros((len(seq_lens), 32), dtype=torch.int32)
+    perm = torch.randperm(n_slots - 1, generator=gen) + 1
+    used = 0
+    for i, n in enumerate(seq_lens):
+        table[i, :n] = perm[used : used + n].to(torch.int32)
+        used += n
+    rows, seq = torch.arange(len(seq_lens)), torch.tensor(seq_lens)
+    full = orc.decode_exact(q, k_slab, v_slab, table, rows, seq)
+    local_table, local_len = torch.zeros_like(table), layout.local_len(seq)
+    for i, n in enumerate(seq_lens):
+        mine = table[i, :n][layout.seq_rank :: layout.tp_seq]
+        local_table[i, : len(mine)] = mine
+    o, lse = orc.decode_exact(layout.shard_q(q), layout.shard_kv(k_slab), layout.shard_kv(v_slab),
+                              local_table, rows, local_len, return_lse=True)
+    if layout.tp_seq == 1:
+        got = tp.tp_attention_exchange(layout, o, None, group, torch.float64)
+    else:
+        got = tp.tp_attention_exchange(layout, o.float(), lse.float(), group, torch.float64, merge_fn=_merge_fn)
+    return (got - full).abs().max().item()
+
+
+@pytest.mark.parametrize("world,n_kv_heads", [(2, 2), (2, 1), (4, 2), (8, 2), (8, 4), (3, 1)])
+def test_ranks_as_threads_of_one_process(world, n_kv_heads):
+    """``LocalGroup``: the ranks of a tensor-parallel group as threads (the one-GPU rehearsal of
+    the multi-GPU path).  The four wrappers, sub-groups, the attention exchange, and a failure on
+    one rank reaching the caller instead of hanging the others."""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    from baby_sglang_amd import tp_runtime as tp
+    from oracle import attn_oracle as orc
+
+    group = tp.LocalGroup(world)
+
+    def rank_body(rank):
+        x = torch.full((3,), float(rank + 1))
+        assert tp.tp_all_reduce_sum(x, group) is x and x.tolist() == [world * (world + 1) / 2] * 3
+        g = tp.tp_all_gather(torch.full((2, 2), float(rank)), group)
+        assert tuple(g.shape) == (2 * world, 2) and all(bool(g[2 * r : 2 * r + 2].eq(r).all()) for r in range(world))
+        b = torch.tensor([7.0 if rank == 1 else 0.0])
+        assert tp.tp_broadcast(b, 1, group) is b and b.item() == 7.0
+        if world % 2 == 0:
+            sub, sub_rank, replica, n_rep = tp.split_tp_groups(2, group)
+            assert (sub_rank, replica, n_rep) == (rank % 2, rank // 2, world // 2)
+            y = torch.tensor([float(rank)])
+            tp.tp_all_reduce_sum(y, sub)
+            assert y.item() == float(4 * replica + 1)
+        layout = tp.TPLayout(rank, world, 4 * n_kv_heads, n_kv_heads)
+        return _sharded_decode_check(tp, orc, layout, group, n_kv_heads, [5, 12, 1, 9, 30])
+
+    errs = group.run(rank_body)
+    assert max(errs) < 2e-6
+
+    def failing(rank):
+        if rank == world - 1:
+            raise KeyError("boom")
+        tp.tp_all_gather(torch.ones(1), group)
+
+    with pytest.raises(KeyError):
+        group.run(failing)

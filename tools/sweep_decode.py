@@ -58,9 +58,9 @@ def main():
                 nt_list = opt.nt.split(",") if variant == 2 else ["-"]
                 for stages, hpt, nt, splits in itertools.product(stage_list, hpt_list, nt_list, (int(s) for s in opt.splits.split(","))):
                     if variant == 2:
-                        os.environ["BSGL_MFMA_NT"] = nt
-                        os.environ["BSGL_MFMA_STAGES"] = stages
-                        os.environ["BSGL_MFMA_HPT"] = hpt
+                        pkg._hip.set_knob("BSGL_MFMA_NT", int(nt))
+                        pkg._hip.set_knob("BSGL_MFMA_STAGES", int(stages))
+                        pkg._hip.set_knob("BSGL_MFMA_HPT", int(hpt))
                     wl.args.variant = variant
                     wl.n_splits = splits
                     ws = pkg._hip.decode_workspace_bytes(args.batch, wl.hq_l, wl.dim, splits, False)
