@@ -21,7 +21,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbsgl_attn.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 BSGL_OK = 0
 BSGL_ERR_BAD_ARG = -1
@@ -64,6 +64,12 @@ SIGNATURES = {
         [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _vp]
         + [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp]
         + [_i32, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _i32, _vp, _sz, _vp],
+    ),
+    "bsgl_paged_decode_static": (
+        ctypes.c_int,
+        [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _vp]
+        + [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp]
+        + [_i32, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _i32, _vp],
     ),
     "bsgl_prefill_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "bsgl_paged_prefill": (
@@ -236,6 +242,7 @@ def paged_decode(
     out_cache_loc: Optional[torch.Tensor] = None,
     fuse_kv_write: bool = False,
     uniform_splits: bool = False,
+    static_scratch: bool = False,
     _plan: Optional[tuple] = None,
 ) -> torch.Tensor:
     """softmax(q K^T * scale) V over page-table rows; returns [B, Hq * D].
@@ -253,7 +260,9 @@ def paged_decode(
     ``workspace`` must have been created zero-filled (``new_decode_workspace``).
     ``n_splits`` bounds the pieces a request's sequence is cut into; pieces have
     one batch-wide length unless ``uniform_splits`` asks for exactly ``n_splits``
-    equal pieces per request.
+    equal pieces per request.  ``static_scratch`` takes the entry point that allocates
+    nothing (``bsgl_paged_decode_static``: the split merge's workspace is an array inside the
+    library, 16 MiB per GPU, shared by all such calls on that GPU); ``out`` must then be given.
     """
     # (this wrapper runs once per layer and decode step beside a ~30 us kernel: every tensor's
     # shape and strides are asked for once)
@@ -286,7 +295,7 @@ def paged_decode(
         n_splits = decode_num_splits(batch, hkv, t_shape[1])
     need = _plan[0] if _plan is not None else decode_workspace_bytes(batch, hq, dim, n_splits, out_dtype != q_dtype)
     ws_bytes = 0
-    if need:
+    if need and not static_scratch:
         if workspace is not None:
             ws_bytes = workspace.numel() * workspace.element_size()
         if ws_bytes < need:
@@ -315,6 +324,18 @@ def paged_decode(
         new = (k_new.data_ptr(), v_new.data_ptr(), kn_stride[0], vn_stride[0], loc.data_ptr())
         if fuse_kv_write:
             variant |= DECODE_FUSE_KV_WRITE
+    if static_scratch:
+        rc = lib.bsgl_paged_decode_static(
+            out.data_ptr(), out.stride(0), lse.data_ptr() if lse is not None else None,
+            q.data_ptr(), q_stride[0], *new,
+            k_slab.data_ptr(), v_slab.data_ptr(), k_stride0, k_shape[0],
+            req_to_token.data_ptr(), t_stride[0], t_shape[0], t_shape[1],
+            req_pool_indices.data_ptr(), seq_lens.data_ptr(),
+            batch, hq, hkv, dim, scale, q_code, _DTYPE_CODE[out_dtype], n_splits, variant,
+            _plan[1] if _plan is not None else _stream_ptr(q.device),
+        )  # fmt: skip
+        _check(rc, "bsgl_paged_decode_static")
+        return out
     rc = lib.bsgl_paged_decode(
         out.data_ptr(), out.stride(0), lse.data_ptr() if lse is not None else None,
         q.data_ptr(), q_stride[0], *new,

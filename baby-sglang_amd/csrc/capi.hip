@@ -200,7 +200,7 @@ int run_decode(bsgl::DecodeArgs& a, int32_t variant, uint32_t* counters, hipStre
 
 extern "C" {
 
-int bsgl_abi_version(void) { return 1; }
+int bsgl_abi_version(void) { return 2; }
 
 void bsgl_debug_decode_trace(void* device_buf) { bsgl::set_decode_trace((uint64_t*)device_buf); }
 
@@ -300,15 +300,46 @@ size_t bsgl_decode_workspace_bytes(int32_t batch, int32_t n_q_heads, int32_t hea
          align_up((size_t)n_splits * rh * 4, 256);
 }
 
-int bsgl_paged_decode(void* out, int64_t out_row_stride, float* lse, const void* q, int64_t q_row_stride,
-                      const void* k_new, const void* v_new, int64_t k_new_row_stride, int64_t v_new_row_stride,
-                      const int32_t* out_cache_loc,
-                      void* k_slab, void* v_slab, int64_t slab_row_stride, int64_t n_slots,
-                      const int32_t* req_to_token, int64_t table_row_stride, int64_t table_rows,
-                      int64_t table_cols, const int64_t* req_pool_indices, const int64_t* seq_lens,
-                      int32_t batch, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim, float scale,
-                      int32_t dtype, int32_t out_dtype, int32_t n_splits, int32_t variant,
-                      void* workspace, size_t workspace_bytes, void* stream) {
+// Scratch of bsgl_paged_decode_static: the decode workspace (tickets, partial rows, their
+// log-sum-exps) as an array of the code object instead of caller memory.  Every GPU the library
+// runs on holds its own copy, at its own address, until the process ends.
+constexpr size_t kStaticScratchBytes = BSGL_STATIC_SCRATCH_BYTES;
+static __device__ __align__(256) __attribute__((used)) unsigned char scratch[kStaticScratchBytes];
+
+namespace {
+
+// The array's name is a host-side stand-in, not a device address: the address is asked for once per
+// device (with that device current) and only that pointer is ever handed to a kernel or a memset.
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[kMaxDevices] = {};
+
+int scratch_of_current_device(void** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return hip_fail("hipGetDevice", e);
+  if (dev < 0 || dev >= kMaxDevices) return fail(BSGL_ERR_UNSUPPORTED, "device ordinal %d outside [0, %d)", dev, kMaxDevices);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (g_scratch_ptr[dev] == nullptr) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return hip_fail("hipGetSymbolAddress(scratch)", e);
+    if (p == nullptr) return fail(BSGL_ERR_HIP, "hipGetSymbolAddress(scratch) gave a null address");
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return BSGL_OK;
+}
+
+int decode_entry(void* out, int64_t out_row_stride, float* lse, const void* q, int64_t q_row_stride,
+                 const void* k_new, const void* v_new, int64_t k_new_row_stride, int64_t v_new_row_stride,
+                 const int32_t* out_cache_loc,
+                 void* k_slab, void* v_slab, int64_t slab_row_stride, int64_t n_slots,
+                 const int32_t* req_to_token, int64_t table_row_stride, int64_t table_rows,
+                 int64_t table_cols, const int64_t* req_pool_indices, const int64_t* seq_lens,
+                 int32_t batch, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim, float scale,
+                 int32_t dtype, int32_t out_dtype, int32_t n_splits, int32_t variant,
+                 void* workspace, size_t workspace_bytes, bool static_scratch, void* stream) {
   if (batch < 0) return fail(BSGL_ERR_BAD_ARG, "batch < 0");
   if (out_dtype != dtype && out_dtype != BSGL_DTYPE_F32)
     return fail(BSGL_ERR_BAD_ARG, "out_dtype must equal dtype or be f32");
@@ -337,6 +368,18 @@ int bsgl_paged_decode(void* out, int64_t out_row_stride, float* lse, const void*
   if (f32_out && (((uintptr_t)out & 15u) || (out_row_stride * 4) % 16))
     return fail(BSGL_ERR_BAD_ARG, "f32 out must be 16-byte aligned with a 16-byte-multiple row stride");
   const size_t need = bsgl_decode_workspace_bytes(batch, n_q_heads, head_dim, n_splits, f32_out);
+  if (static_scratch && need > 0) {
+    if (need > kStaticScratchBytes)
+      return fail(BSGL_ERR_WORKSPACE, "bsgl_paged_decode_static: batch %d x %d q heads x %d splits needs %zu bytes of scratch, "
+                  "the library's array holds %zu; use bsgl_paged_decode with a workspace, or fewer splits",
+                  batch, n_q_heads, n_splits, need, kStaticScratchBytes);
+    if (int rc = scratch_of_current_device(&workspace)) return rc;
+    workspace_bytes = kStaticScratchBytes;
+    // the array keeps the last call's contents; the tickets of this call's rows must start at zero
+    const size_t ticket_bytes = align_up((size_t)batch * (size_t)n_kv_heads * 4, 256);
+    const hipError_t em = hipMemsetAsync(workspace, 0, ticket_bytes < kCounterBytes ? ticket_bytes : kCounterBytes, (hipStream_t)stream);
+    if (em != hipSuccess) return hip_fail("hipMemsetAsync(scratch tickets)", em);
+  }
   if (need > 0 && (workspace == nullptr || workspace_bytes < need || !aligned16(workspace)))
     return fail(BSGL_ERR_WORKSPACE, "decode with %d splits needs a 16-byte aligned workspace of %zu bytes (got %zu)", n_splits, need, workspace ? workspace_bytes : (size_t)0);
   a.out = out;
@@ -359,6 +402,37 @@ int bsgl_paged_decode(void* out, int64_t out_row_stride, float* lse, const void*
   a.ws_o = need ? (float*)((char*)workspace + cb) : nullptr;
   a.ws_lse = need ? (float*)((char*)workspace + cb + align_up((size_t)n_splits * rh * partial_row_width(head_dim) * 4, 256)) : nullptr;
   return run_decode(a, variant, need ? (uint32_t*)workspace : nullptr, (hipStream_t)stream);
+}
+
+}  // namespace
+
+int bsgl_paged_decode(void* out, int64_t out_row_stride, float* lse, const void* q, int64_t q_row_stride,
+                      const void* k_new, const void* v_new, int64_t k_new_row_stride, int64_t v_new_row_stride,
+                      const int32_t* out_cache_loc,
+                      void* k_slab, void* v_slab, int64_t slab_row_stride, int64_t n_slots,
+                      const int32_t* req_to_token, int64_t table_row_stride, int64_t table_rows,
+                      int64_t table_cols, const int64_t* req_pool_indices, const int64_t* seq_lens,
+                      int32_t batch, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim, float scale,
+                      int32_t dtype, int32_t out_dtype, int32_t n_splits, int32_t variant,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+  return decode_entry(out, out_row_stride, lse, q, q_row_stride, k_new, v_new, k_new_row_stride, v_new_row_stride,
+                      out_cache_loc, k_slab, v_slab, slab_row_stride, n_slots, req_to_token, table_row_stride,
+                      table_rows, table_cols, req_pool_indices, seq_lens, batch, n_q_heads, n_kv_heads, head_dim,
+                      scale, dtype, out_dtype, n_splits, variant, workspace, workspace_bytes, false, stream);
+}
+
+int bsgl_paged_decode_static(void* out, int64_t out_row_stride, float* lse, const void* q, int64_t q_row_stride,
+                             const void* k_new, const void* v_new, int64_t k_new_row_stride, int64_t v_new_row_stride,
+                             const int32_t* out_cache_loc,
+                             void* k_slab, void* v_slab, int64_t slab_row_stride, int64_t n_slots,
+                             const int32_t* req_to_token, int64_t table_row_stride, int64_t table_rows,
+                             int64_t table_cols, const int64_t* req_pool_indices, const int64_t* seq_lens,
+                             int32_t batch, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim, float scale,
+                             int32_t dtype, int32_t out_dtype, int32_t n_splits, int32_t variant, void* stream) {
+  return decode_entry(out, out_row_stride, lse, q, q_row_stride, k_new, v_new, k_new_row_stride, v_new_row_stride,
+                      out_cache_loc, k_slab, v_slab, slab_row_stride, n_slots, req_to_token, table_row_stride,
+                      table_rows, table_cols, req_pool_indices, seq_lens, batch, n_q_heads, n_kv_heads, head_dim,
+                      scale, dtype, out_dtype, n_splits, variant, nullptr, 0, true, stream);
 }
 
 static int32_t prefill_row_splits(int32_t total_q_tokens, int32_t max_context_len) {

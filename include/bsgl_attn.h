@@ -158,6 +158,40 @@ int bsgl_paged_decode(void* out /*device*/, int64_t out_row_stride,
                       void* workspace /*device*/, size_t workspace_bytes, void* stream);
 
 /*
+ * bsgl_paged_decode without a caller workspace and without any allocation.  No counterpart in
+ * the reference: it is for callers that cannot allocate device memory -- code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc -- and that have no workspace
+ * tensor to hand in.  Same arguments, kernels and results (bit for bit) as bsgl_paged_decode;
+ * the tickets, partial rows and log-sum-exps of the split merge live in an array inside the
+ * library's code object instead: BSGL_STATIC_SCRATCH_BYTES per GPU, held by every GPU the library
+ * runs on until the process ends.  The call makes no hipMalloc / hipFree and calls no allocating
+ * routine; it enqueues one hipMemsetAsync (this call's tickets) and the decode launch on `stream`.
+ * The first call on a device looks the array's address up (hipGetSymbolAddress, once per device,
+ * with that device current -- the caller must have the stream's device current, as for every
+ * entry point).
+ * Limits: bsgl_decode_workspace_bytes(batch, n_q_heads, head_dim, n_splits, out_dtype != dtype)
+ * must not exceed BSGL_STATIC_SCRATCH_BYTES, else BSGL_ERR_WORKSPACE (nothing is launched).  All
+ * calls on one GPU share that GPU's array: calls that may overlap on one GPU (two streams, two
+ * threads) race on it and must use bsgl_paged_decode with workspaces of their own.
+ */
+#define BSGL_STATIC_SCRATCH_BYTES ((size_t)16 << 20)
+int bsgl_paged_decode_static(void* out /*device*/, int64_t out_row_stride,
+                             float* lse /*device or NULL*/,
+                             const void* q /*device*/, int64_t q_row_stride,
+                             const void* k_new /*device or NULL*/, const void* v_new /*device or NULL*/,
+                             int64_t k_new_row_stride, int64_t v_new_row_stride,
+                             const int32_t* out_cache_loc /*device or NULL, [batch]*/,
+                             void* k_slab /*device*/, void* v_slab /*device*/,
+                             int64_t slab_row_stride, int64_t n_slots,
+                             const int32_t* req_to_token /*device*/, int64_t table_row_stride,
+                             int64_t table_rows, int64_t table_cols,
+                             const int64_t* req_pool_indices /*device, [batch]*/,
+                             const int64_t* seq_lens /*device, [batch]*/,
+                             int32_t batch, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim,
+                             float scale, int32_t dtype, int32_t out_dtype, int32_t n_splits,
+                             int32_t variant, void* stream);
+
+/*
  * Workspace for bsgl_paged_prefill (host arithmetic).
  */
 size_t bsgl_prefill_workspace_bytes(int32_t batch, int32_t total_q_tokens, int32_t n_q_heads,
