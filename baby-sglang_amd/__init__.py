@@ -11,7 +11,7 @@ from . import _hip
 from .attn_backend import SimpleAttentionBackend
 from .forward_batch import SimplifiedForwardBatch
 from .memory_pool import BaseTokenToKVPool, MHATokenToKVPool, ReqToTokenPool
-from .qwen2_hip import BabyQwen2ForCausalLM
+from .qwen2_hip import BabyQwen2ForCausalLM, shard_state_dict
 from .tp_runtime import (
     LocalGroup,
     TPLayout,
@@ -28,6 +28,7 @@ __all__ = [
     "_hip",
     "SimpleAttentionBackend",
     "BabyQwen2ForCausalLM",
+    "shard_state_dict",
     "SimplifiedForwardBatch",
     "BaseTokenToKVPool",
     "MHATokenToKVPool",

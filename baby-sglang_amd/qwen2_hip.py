@@ -14,6 +14,14 @@ token.  What differs is what runs between the GEMMs:
 GEMMs, embedding lookup and SiLU stay torch ops (rocBLAS / hipBLASLt): plumbing here.
 ``inv_freq`` is a module buffer as in the reference, so ``model.to(torch.bfloat16)``
 rounds it to bf16 exactly as the reference's does.
+
+Tensor parallel (the reference has the collectives, tp_runtime.py:10-51, and no sharded model):
+``BabyQwen2ForCausalLM(config, tp_layout=TPLayout(rank, world, Hq, Hkv, replicate_kv=True),
+tp_group=group)`` builds one rank's shard -- column-parallel q / k / v and gate / up
+projections, row-parallel ``o_proj`` and ``down_proj`` each followed by ``tp_all_reduce_sum``
+(tp_runtime.py:28-33) -- over a KV pool of ``tp_layout.local_kv_heads`` heads; embeddings, norms and
+the vocabulary projection are replicated.  ``shard_state_dict`` cuts a whole (reference)
+``state_dict`` down to a rank's.
 """
 
 from __future__ import annotations
@@ -27,6 +35,18 @@ import torch.nn.functional as F
 from . import _hip
 from .attn_backend import SimpleAttentionBackend
 from .forward_batch import SimplifiedForwardBatch
+from .tp_runtime import TPLayout, tp_all_reduce_sum
+
+
+def _model_layout(tp_layout: Optional[TPLayout]) -> Optional[TPLayout]:
+    if tp_layout is None or tp_layout.world == 1:
+        return None
+    if tp_layout.tp_seq != 1:
+        raise NotImplementedError(
+            "a tensor-parallel model shards heads (TPLayout(..., replicate_kv=True)); sequence slices "
+            "inside a kv head are the attention path's own layout and have no extend (prefill) form"
+        )
+    return tp_layout
 
 
 class RMSNorm(nn.Module):
@@ -98,11 +118,17 @@ class BabyRadixAttention(nn.Module):
 
 class Qwen2Attention(nn.Module):
     def __init__(self, hidden_size: int, num_heads: int, num_kv_heads: int, layer_id: int = 0,
-                 rope_theta: float = 1000000, rope_scaling=None, max_position_embeddings: int = 32768):  # fmt: skip
+                 rope_theta: float = 1000000, rope_scaling=None, max_position_embeddings: int = 32768,
+                 tp_layout: Optional[TPLayout] = None, tp_group=None):  # fmt: skip
         super().__init__()
+        self.head_dim = hidden_size // num_heads
+        self.tp_layout, self.tp_group = _model_layout(tp_layout), tp_group
+        if self.tp_layout is not None:
+            # this rank's heads: the projections are cut by output column (q / k / v) and input
+            # column (o_proj) accordingly
+            num_heads, num_kv_heads = self.tp_layout.local_q_heads, self.tp_layout.local_kv_heads
         self.num_heads = num_heads
         self.num_kv_heads = num_kv_heads
-        self.head_dim = hidden_size // num_heads
         self.scaling = self.head_dim**-0.5
         self.qkv_proj = QKVLinear(hidden_size, num_heads, num_kv_heads, self.head_dim, bias=True)
         self.o_proj = nn.Linear(num_heads * self.head_dim, hidden_size, bias=False)
@@ -125,24 +151,37 @@ class Qwen2Attention(nn.Module):
             q, k, v = _hip.rope_kv_write(qkv, positions, self.rotary_emb.inv_freq, self.num_heads,
                                          self.num_kv_heads, self.head_dim, return_kv=True)  # fmt: skip
             attn = self.attn(q, k, v, forward_batch)
-        return self.o_proj(attn)
+        out = self.o_proj(attn)
+        if self.tp_layout is not None:
+            # row-parallel projection: every rank holds the partial sum over its heads
+            out = tp_all_reduce_sum(out, self.tp_group)
+        return out
 
 
 class Qwen2MLP(nn.Module):
-    def __init__(self, hidden_size: int, intermediate_size: int, hidden_act: str = "silu"):
+    def __init__(self, hidden_size: int, intermediate_size: int, hidden_act: str = "silu",
+                 tp_layout: Optional[TPLayout] = None, tp_group=None):
         super().__init__()
         if hidden_act != "silu":
             raise ValueError(f"Unsupported activation: {hidden_act}. Only silu supported.")
+        self.tp_layout, self.tp_group = _model_layout(tp_layout), tp_group
+        if self.tp_layout is not None:
+            if intermediate_size % self.tp_layout.world:
+                raise ValueError(f"intermediate size {intermediate_size} does not divide over {self.tp_layout.world} ranks")
+            intermediate_size //= self.tp_layout.world
         self.gate_up_proj = GateUpLinear(hidden_size, intermediate_size, bias=False)
         self.down_proj = nn.Linear(intermediate_size, hidden_size, bias=False)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         gate, up = self.gate_up_proj(x)
-        return self.down_proj(F.silu(gate) * up)
+        out = self.down_proj(F.silu(gate) * up)
+        if self.tp_layout is not None:
+            out = tp_all_reduce_sum(out, self.tp_group)
+        return out
 
 
 class Qwen2DecoderLayer(nn.Module):
-    def __init__(self, config, layer_id: int = 0):
+    def __init__(self, config, layer_id: int = 0, tp_layout: Optional[TPLayout] = None, tp_group=None):
         super().__init__()
         self.self_attn = Qwen2Attention(
             hidden_size=config.hidden_size,
@@ -152,8 +191,11 @@ class Qwen2DecoderLayer(nn.Module):
             rope_theta=getattr(config, "rope_theta", 1000000),
             rope_scaling=getattr(config, "rope_scaling", None),
             max_position_embeddings=getattr(config, "max_position_embeddings", 32768),
+            tp_layout=tp_layout,
+            tp_group=tp_group,
         )
-        self.mlp = Qwen2MLP(config.hidden_size, config.intermediate_size, getattr(config, "hidden_act", "silu"))
+        self.mlp = Qwen2MLP(config.hidden_size, config.intermediate_size, getattr(config, "hidden_act", "silu"),
+                            tp_layout=tp_layout, tp_group=tp_group)
         self.input_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self.post_attention_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
 
@@ -169,12 +211,14 @@ class Qwen2DecoderLayer(nn.Module):
 
 
 class BabyQwen2Model(nn.Module):
-    def __init__(self, config):
+    def __init__(self, config, tp_layout: Optional[TPLayout] = None, tp_group=None):
         super().__init__()
         self.config = config
         self.vocab_size = config.vocab_size
         self.embed_tokens = nn.Embedding(config.vocab_size, config.hidden_size)
-        self.layers = nn.ModuleList(Qwen2DecoderLayer(config, layer_id=i) for i in range(config.num_hidden_layers))
+        self.layers = nn.ModuleList(
+            Qwen2DecoderLayer(config, layer_id=i, tp_layout=tp_layout, tp_group=tp_group) for i in range(config.num_hidden_layers)
+        )
         self.norm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
 
     def forward(self, input_ids, positions, forward_batch, input_embeds=None):
@@ -186,11 +230,40 @@ class BabyQwen2Model(nn.Module):
         return hidden_states
 
 
+def shard_state_dict(state_dict, config, tp_layout: TPLayout):
+    """One rank's part of a whole model's ``state_dict`` (reference parameter names): the rows of
+    ``qkv_proj`` (and its bias) that make this rank's q, k and v heads, the columns of ``o_proj``
+    that take its q heads, its slice of the MLP's intermediate columns; everything else whole."""
+    lay = _model_layout(tp_layout)
+    if lay is None:
+        return dict(state_dict)
+    hq, hkv = config.num_attention_heads, config.num_key_value_heads
+    dim = getattr(config, "head_dim", None) or config.hidden_size // hq
+    q_lo, q_hi = (x * dim for x in lay.q_head_range)
+    kv_lo, kv_hi = (x * dim for x in lay.kv_head_range)
+    inter = config.intermediate_size
+    i_lo, i_hi = lay.rank * inter // lay.world, (lay.rank + 1) * inter // lay.world
+    out = {}
+    for name, w in state_dict.items():
+        if name.endswith("qkv_proj.qkv_proj.weight") or name.endswith("qkv_proj.qkv_proj.bias"):
+            q, k, v = w.split([hq * dim, hkv * dim, hkv * dim], dim=0)
+            w = torch.cat((q[q_lo:q_hi], k[kv_lo:kv_hi], v[kv_lo:kv_hi]), dim=0)
+        elif name.endswith("self_attn.o_proj.weight"):
+            w = w[:, q_lo:q_hi]
+        elif name.endswith("gate_up_proj.gate_up_proj.weight"):
+            gate, up = w.chunk(2, dim=0)
+            w = torch.cat((gate[i_lo:i_hi], up[i_lo:i_hi]), dim=0)
+        elif name.endswith("mlp.down_proj.weight"):
+            w = w[:, i_lo:i_hi]
+        out[name] = w.contiguous()
+    return out
+
+
 class BabyQwen2ForCausalLM(nn.Module):
-    def __init__(self, config):
+    def __init__(self, config, tp_layout: Optional[TPLayout] = None, tp_group=None):
         super().__init__()
         self.config = config
-        self.model = BabyQwen2Model(config)
+        self.model = BabyQwen2Model(config, tp_layout=tp_layout, tp_group=tp_group)
         if getattr(config, "tie_word_embeddings", False):
             self.lm_head = self.model.embed_tokens
         else:

@@ -273,16 +273,26 @@ def tp_broadcast(x: torch.Tensor, src: int, tp_group) -> torch.Tensor:
 
 @dataclass(frozen=True)
 class TPLayout:
-    """Which kv heads and which token positions a rank owns.
+    """Which q heads, kv heads and token positions a rank owns.
 
-    world = tp_kv * tp_seq; ranks of one kv-head shard are consecutive:
-    ``rank = kv_rank * tp_seq + seq_rank``.
+    Ranks of one kv-head shard are consecutive: ``rank = kv_rank * ranks_per_kv + i``.  kv heads
+    are split first.  When the world is larger than the kv-head count there are two ways on:
+
+    * ``replicate_kv=False`` (default; the attention path's own layout): the ranks of a kv head
+      all take ALL its q heads and split every request's TOKENS round-robin by position
+      (``tp_seq`` slices, each rank its own pool and local page table); partial ``(o, lse)``
+      states are merged across the slices.  HBM bytes per rank keep falling with the world.
+    * ``replicate_kv=True`` (what a whole tensor-parallel MODEL uses: column-parallel q / k / v
+      projections, row-parallel output projection): the ranks of a kv head split its Q HEADS and
+      each keeps a copy of the kv head; page tables and batches are the same on every rank and
+      nothing is merged, but a rank's KV bytes stop falling once the world exceeds the kv heads.
     """
 
     rank: int
     world: int
     n_q_heads: int
     n_kv_heads: int
+    replicate_kv: bool = False
 
     def __post_init__(self):
         if self.world < 1 or not (0 <= self.rank < self.world):
@@ -295,22 +305,30 @@ class TPLayout:
                 f"world {self.world} cannot shard {self.n_kv_heads} kv heads: it must divide "
                 "the kv-head count or be a multiple of it"
             )
+        if self.replicate_kv and (self.n_q_heads // self.n_kv_heads) % (self.world // kv):
+            raise ValueError(
+                f"world {self.world} cannot split the {self.n_q_heads // self.n_kv_heads} q heads of a kv head evenly"
+            )
 
     @property
     def tp_kv(self) -> int:
         return min(self.world, self.n_kv_heads)
 
     @property
-    def tp_seq(self) -> int:
+    def ranks_per_kv(self) -> int:
         return self.world // self.tp_kv
 
     @property
+    def tp_seq(self) -> int:
+        return 1 if self.replicate_kv else self.ranks_per_kv
+
+    @property
     def kv_rank(self) -> int:
-        return self.rank // self.tp_seq
+        return self.rank // self.ranks_per_kv
 
     @property
     def seq_rank(self) -> int:
-        return self.rank % self.tp_seq
+        return 0 if self.replicate_kv else self.rank % self.ranks_per_kv
 
     @property
     def group(self) -> int:
@@ -322,6 +340,8 @@ class TPLayout:
 
     @property
     def local_q_heads(self) -> int:
+        if self.replicate_kv:
+            return self.n_q_heads // self.world
         return self.local_kv_heads * self.group
 
     @property
@@ -331,6 +351,8 @@ class TPLayout:
 
     @property
     def q_head_range(self) -> Tuple[int, int]:
+        if self.replicate_kv:
+            return self.rank * self.local_q_heads, (self.rank + 1) * self.local_q_heads
         lo, hi = self.kv_head_range
         return lo * self.group, hi * self.group
 

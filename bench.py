@@ -56,9 +56,9 @@ def parse_args():
     ap.add_argument("--no-fuse", action="store_true", help="KV write as its own launch instead of inside the decode kernel")
     ap.add_argument("--no-extras", action="store_true", help="skip the contiguous-table and eager/graph side measurements")
     ap.add_argument("--tp", type=int, default=0,
-                    help="ranks per tensor-parallel group (0 = the kv-head count, 2 for these shapes, or N if smaller); "
-                         "N / tp groups run side by side as replicas on different requests.  --tp N puts all N "
-                         "ranks in one group (kv heads first, then sequence slices)")
+                    help="ranks per tensor-parallel group (0 = N: ONE group of all ranks, kv heads first, then sequence "
+                         "slices inside a kv head).  A smaller value runs N / tp such groups side by side as replicas on "
+                         "different requests (--tp 2: each rank owns a whole kv head, no sequence slices)")
     ap.add_argument("--collectives", choices=["auto", "torch", "capi"], default="auto",
                     help="N > 1: torch = torch.distributed (RCCL) issued from Python per layer; capi = the library's own "
                          "RCCL communicator (bsgl_all_gather enqueued on the launch stream, no per-call work objects; "
@@ -365,40 +365,114 @@ def extend_extras(dev, reps=5):
 CAPI_NOTE = [None]
 
 
-def try_capi_collectives(pkg, tp_group, world_group, tp_rank, dev):
-    """Bring up the library's own RCCL communicator for this rank's tensor-parallel group and
-    check its first all-gather against torch.distributed's; every rank of the job learns whether
-    ALL ranks succeeded (one MIN all-reduce), so the ranks always agree on the path taken."""
+def _all_ok(ok, world_group, dev):
+    """MIN over every rank of the job: did the step just taken succeed everywhere?"""
     dist = torch.distributed
-    ok = 1
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if dist.get_backend(world_group) != "gloo" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=world_group)
+    return int(flag.item()) == 1
+
+
+def try_capi_collectives(pkg, tp_group, world_group, tp_rank, dev):
+    """Bring up the library's own RCCL communicator for this rank's tensor-parallel group and check
+    its first all-gather against torch.distributed's.  Every rank makes the SAME sequence of
+    collective calls whatever happens locally -- a failure is carried as a marker and agreed on by
+    a MIN all-reduce over the whole job before the next step -- so a rank that fails can never
+    leave its peers inside a collective it skipped: (1) every rank loads RCCL (making an id does
+    that), rank 0 of the group broadcasts its id or a failure marker; agree.  (2) every rank enters
+    the blocking communicator set-up; agree.  (3) every rank runs both gathers and compares; agree."""
+    dist = torch.distributed
+    hip, tpr = pkg._hip, pkg.tp_runtime
+    src = dist.get_global_rank(tp_group, 0) if tp_group is not None else 0
+    # (1) id hand-over
+    ok, ident = True, None
     try:
-        pkg.use_capi_collectives(tp_group)
-        probe = torch.full((4, 8), float(tp_rank + 1), device=dev, dtype=torch.bfloat16)
-        got = pkg._hip.all_gather(probe)
-        want = torch.empty_like(got)
-        dist.all_gather_into_tensor(want, probe, group=tp_group)
+        ident = hip.comm_unique_id()
+    except Exception as exc:  # RCCL not loadable here
+        ok, CAPI_NOTE[0] = False, repr(exc)[:300]
+    box = [ident if (tp_rank == 0 and ok) else None]
+    dist.broadcast_object_list(box, src=src, group=tp_group)
+    ok = ok and box[0] is not None
+    if not _all_ok(ok, world_group, dev):
+        CAPI_NOTE[0] = CAPI_NOTE[0] or "another rank could not load RCCL through the library"
+        return False
+    # (2) communicator (blocks until every rank of the group has entered: all of them do)
+    world = dist.get_world_size(group=tp_group)
+    try:
+        hip.comm_init(tp_rank, world, box[0])
+    except Exception as exc:
+        ok, CAPI_NOTE[0] = False, repr(exc)[:300]
+    if not _all_ok(ok, world_group, dev):
+        CAPI_NOTE[0] = CAPI_NOTE[0] or "another rank could not bring up the library's communicator"
+        if ok:
+            hip.comm_destroy()
+        return False
+    # (3) probe gather, both ways, on every rank
+    probe = torch.full((4, 8), float(tp_rank + 1), device=dev, dtype=torch.bfloat16)
+    want = torch.empty((world * 4, 8), device=dev, dtype=torch.bfloat16)
+    dist.all_gather_into_tensor(want, probe, group=tp_group)
+    try:
+        got = hip.all_gather(probe)
         torch.cuda.synchronize()
         if not torch.equal(got, want):
-            ok, CAPI_NOTE[0] = 0, "the library's all-gather disagreed with torch.distributed's"
-    except Exception as exc:  # RCCL missing, communicator refused, ...: the torch.distributed path remains
-        ok, CAPI_NOTE[0] = 0, repr(exc)[:300]
-    flag = torch.tensor([ok], dtype=torch.int32, device=dev if dist.get_backend(world_group) != "gloo" else "cpu")
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=world_group)
-    if int(flag.item()) == 0:
-        pkg.tp_runtime.release_capi_collectives()
-        pkg._hip.comm_destroy()
+            ok, CAPI_NOTE[0] = False, "the library's all-gather disagreed with torch.distributed's"
+    except Exception as exc:
+        ok, CAPI_NOTE[0] = False, repr(exc)[:300]
+    if not _all_ok(ok, world_group, dev):
+        CAPI_NOTE[0] = CAPI_NOTE[0] or "the library's all-gather failed its check on another rank"
+        hip.comm_destroy()
         return False
+    tpr._CAPI_GROUP[0], tpr._CAPI_GROUP[1] = tp_group, True
     return True
 
 
 def read_traffic():
-    """HBM bytes per decode launch from a committed rocprofv3 --pmc summary, if any."""
+    """HBM bytes per decode launch from the committed rocprofv3 --pmc summary (PMC counters cannot
+    be read from inside a timed run), and where that number comes from."""
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
     try:
         with open(path) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
+            t = json.load(f)
+        src = f"profiles/traffic_latest.json (rocprofv3 --pmc passes: {t.get('source', 'tools/pmc_traffic.sh')}; library at commit {t.get('commit', 'unrecorded')})"
+        return t.get("hbm_bytes_per_launch"), src
     except (OSError, ValueError):
-        return None
+        return None, None
+
+
+def measure(args, wl, world, world_group, tp_group, tp, layout, n_replicas, dev, pkg, tp_rank):
+    """Time args.steps steps of `wl`; returns the fields of one measurement."""
+    note = None
+    collectives = None
+    mode = args.mode
+    if tp > 1:
+        want_capi = args.collectives in ("auto", "capi") and layout.tp_seq == 1
+        got_capi = want_capi and try_capi_collectives(pkg, tp_group, world_group, tp_rank, dev)
+        collectives = "capi" if got_capi else "torch"
+        if want_capi and not got_capi:
+            note = CAPI_NOTE[0] or "another rank could not bring up the library's communicator"
+        # torch.distributed calls are issued from Python each layer; the library's own enqueue-only
+        # collectives may also be captured with the step
+        mode = "graph" if (got_capi and args.tp_graph) else "eager"
+    runner = make_runner(wl, mode, tp_group)
+    dt = timed_steps(runner, args.steps, args.warmup, world)
+    rccl_ranks = None
+    if tp > 1:
+        backend = torch.distributed.get_backend(tp_group)
+        rccl_ranks = pkg._hip.comm_world() if collectives == "capi" else (torch.distributed.get_world_size(group=tp_group) if backend == "nccl" else 0)
+    return dict(dt=dt, event_ms=LAST_EVENT_MS[0], mode=mode, collectives=collectives, note=note, rccl_ranks=rccl_ranks)
+
+
+HBM_ACHIEVABLE_GBS = 6290.0  # what a streaming copy reaches on MI355X (measured figure of the hardware guide)
+
+
+def parallelism_label(world, n_replicas, tp, layout):
+    if world == 1:
+        return "single GPU"
+    how = ("no exchange" if tp == 1 else
+           "one all-gather of the output rows per layer" if layout.tp_seq == 1 else
+           "per layer an all-to-all of partial (o, lse) states among the ranks of a kv head, a merge, and an all-gather of the merged rows")
+    groups = "ONE tensor-parallel group of all ranks" if n_replicas == 1 else f"{n_replicas} replica(s) x tp{tp}"
+    return f"{groups}: tp{tp} = {layout.tp_kv} kv-head shards x {layout.tp_seq} sequence slices; {how}"
 
 
 def main():
@@ -419,37 +493,33 @@ def main():
     rank, world, world_group = pkg.init_tp()
     dev = torch.device("cuda", torch.cuda.current_device())
     per_gpu_batch = args.batch
-    # Tensor parallel up to the kv-head count (each rank owns whole kv heads: one all-gather of the
-    # output rows per layer); beyond it the job grows by replicas of that group on other requests,
-    # which are independent and exchange nothing.  --tp N makes one group of all ranks instead
-    # (sequence slices inside a kv head: an all-to-all of partial states as well).
-    tp = args.tp if args.tp > 0 else min(world, 2)
+    # N > 1: ONE tensor-parallel group of all N ranks (BASELINE configs[3]: TP = 2 / 4 / 8): kv heads
+    # are split first (2 for these shapes), the ranks of a kv head then split every request's tokens
+    # round-robin by position.  --tp T < N runs N / T such groups as replicas on different requests.
+    tp = args.tp if args.tp > 0 else world
     tp_group, tp_rank, replica, n_replicas = pkg.split_tp_groups(tp, world_group)
-    if args.scaling == "weak":
-        # every rank holds its kv-head / sequence share of tp x batch requests, i.e. the KV bytes
-        # of `batch` whole requests
-        args.batch *= tp
-    elif n_replicas > 1:
-        if args.batch % n_replicas:
-            raise SystemExit("--scaling strong: the batch must divide over the replicas")
-        args.batch //= n_replicas
-    layout = pkg.TPLayout(tp_rank, tp, 12, 2)
-    args.seed_rank = rank  # replicas hold different requests
-    job_batch = args.batch * n_replicas
-    wl = Workload(args, dev, layout)
+    base_batch = args.batch
 
-    collectives_note = None
-    if tp > 1:
-        want_capi = args.collectives in ("auto", "capi") and layout.tp_seq == 1
-        args.collectives = "capi" if want_capi and try_capi_collectives(pkg, tp_group, world_group, tp_rank, dev) else "torch"
-        if want_capi and args.collectives == "torch":
-            collectives_note = CAPI_NOTE[0] or "another rank could not bring up the library's communicator"
-        # torch.distributed calls are issued from Python each layer; the library's own enqueue-only
-        # collectives may also be captured with the step
-        args.mode = "graph" if (args.collectives == "capi" and args.tp_graph) else "eager"
-    runner = make_runner(wl, args.mode, tp_group)
-    dt = timed_steps(runner, args.steps, args.warmup, world)
-    event_ms_per_step = LAST_EVENT_MS[0] / args.steps
+    def sized(tp_, n_replicas_):
+        a = argparse.Namespace(**vars(args))
+        if args.scaling == "weak":
+            # every rank holds its kv-head / sequence share of tp x batch requests, i.e. the KV
+            # bytes of `batch` whole requests, whatever N
+            a.batch = base_batch * tp_
+        elif n_replicas_ > 1:
+            if base_batch % n_replicas_:
+                raise SystemExit("--scaling strong: the batch must divide over the replicas")
+            a.batch = base_batch // n_replicas_
+        a.seed_rank = rank  # replicas hold different requests
+        return a
+
+    wargs = sized(tp, n_replicas)
+    layout = pkg.TPLayout(tp_rank, tp, 12, 2)
+    job_batch = wargs.batch * n_replicas
+    wl = Workload(wargs, dev, layout)
+    m = measure(wargs, wl, world, world_group, tp_group, tp, layout, n_replicas, dev, pkg, tp_rank)
+    dt = m["dt"]
+    event_ms_per_step = m["event_ms"] / args.steps
     ms_per_step = dt / args.steps * 1e3
     tokens_per_s = job_batch * args.steps / dt
 
@@ -467,20 +537,18 @@ def main():
         "dtype": "bf16",
         "data": "synthetic (N(0,1) q/k/v and KV slabs, random-permutation page table, torch.manual_seed)",
         "config": {
-            "workload": f"BASELINE configs[2]: Qwen2.5-1.5B bf16 decode, batch={job_batch}, seq={args.seq}, "
-                        f"{args.layers} layers x (KV write + paged decode attention), Hq=12 Hkv=2 D=128, "
-                        f"page table={args.table}, kv_layout={args.kv_layout}",
+            "workload": f"BASELINE configs[{2 if world == 1 else 3}]: Qwen2.5-1.5B bf16 decode, batch={job_batch}, seq={args.seq}, "
+                        f"{args.layers} layers x (KV write + paged decode attention"
+                        + ("" if world == 1 else " + tensor-parallel exchange of the output rows") +
+                        f"), Hq=12 Hkv=2 D=128, page table={args.table}, kv_layout={args.kv_layout}",
             "global_batch": job_batch,
             "kv_bytes_per_gpu_equal_to_batch": per_gpu_batch if args.scaling == "weak" or world == 1 else job_batch / world,
             "seq_len": args.seq,
-            "parallelism": "single GPU" if world == 1 else
-                           f"{n_replicas} replica(s) x tp{tp} ({layout.tp_kv} kv-head shards x {layout.tp_seq} sequence slices); "
-                           + ("no exchange" if tp == 1 else
-                              "one all-gather of the output rows per layer inside each tp group" if layout.tp_seq == 1 else
-                              "per layer an all-to-all of partial states inside each kv head's ranks and an all-gather of the merged rows"),
-            "launch": args.mode,
-            "collectives": args.collectives if tp > 1 else None,
-            "collectives_note": collectives_note,
+            "parallelism": parallelism_label(world, n_replicas, tp, layout),
+            "launch": m["mode"],
+            "collectives": m["collectives"],
+            "collectives_note": m["note"],
+            "rccl_ranks": m["rccl_ranks"],
             "n_splits": wl.n_splits,
             "decode_variant": args.variant,
         },
@@ -490,25 +558,29 @@ def main():
         # Dominant kernel = the decode kernel, launched once per layer (it also stores the new
         # token and merges its splits).  Its average launch duration is the HIP-event time of the
         # timed region divided by the launches in it; at one GPU the region holds nothing else, so
-        # this is the kernel time plus the ~1.5 us boundary between dependent launches (an upper
-        # bound on what rocprofv3 reports for the kernel alone).  With several GPUs the region also
-        # holds the collectives, so the launches are timed on their own there.
+        # this is the kernel time plus the boundary between dependent launches (an upper bound on
+        # what rocprofv3 reports for the kernel alone).  With several GPUs the region also holds
+        # the collectives, so the launches are timed on their own there (this rank's GPU).
         if tp == 1:
             ev_ms = event_ms_per_step / args.layers
         else:
             ev_ms = kernel_event_times(wl, max(2, min(args.steps, 10)))
         total_b, kv_b = wl.algorithmic_bytes_per_layer()
         achieved = total_b / (ev_ms * 1e-3) / 1e9
+        traffic, traffic_source = read_traffic() if world == 1 else (None, None)
         result["roofline"] = {
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": read_traffic() if world == 1 else None,
+            "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
+            "achievable": HBM_ACHIEVABLE_GBS,
+            "traffic": traffic,
+            "traffic_source": traffic_source,
             "kernel": "decode_mfma_kernel (paged decode of one layer incl. new-token KV write and split merge); "
                       "HIP events over the timed region / launches" if world == 1 else
-                      "decode launches of one layer, HIP events around each call",
+                      "decode launches of one layer on this rank's GPU (per-GPU figure), HIP events around each call",
             "algorithmic_bytes_per_launch": total_b,
             "kv_bytes_per_launch": kv_b,
             "avg_launch_us": ev_ms * 1e3,
@@ -518,6 +590,45 @@ def main():
             # the exchange step broken out: decode launches alone vs the whole step
             result["attention_only_ms_per_step"] = ev_ms * args.layers
             result["exchange_ms_per_step"] = max(0.0, ms_per_step - ev_ms * args.layers)
+
+    if world > 2 and args.tp == 0 and not args.no_extras and args.scaling == "weak":
+        # Beside the tensor-parallel line: the same GPUs as REPLICAS of a two-rank group (each rank a
+        # whole kv head, no sequence slices; replicas serve different requests and exchange nothing).
+        # Not config 4 -- its curve is linear by construction -- but what a serving stack would run.
+        extras = result.setdefault("extras", {})
+        if rank == 0:
+            # this side measurement makes new process groups and collectives of its own: should it
+            # stall, the line measured so far still goes out (and the job is ended)
+            import signal
+
+            def give_up(signum, frame):
+                extras["replicas_x_tp2_error"] = "timed out"
+                json_out.write(json.dumps(result) + "\n")
+                json_out.flush()
+                os._exit(3)
+
+            signal.signal(signal.SIGALRM, give_up)
+            signal.alarm(240)
+        try:
+            pkg.tp_runtime.release_capi_collectives()
+            g2, r2, rep2, nrep2 = pkg.split_tp_groups(2, world_group)
+            a2 = sized(2, nrep2)
+            lay2 = pkg.TPLayout(r2, 2, 12, 2)
+            del wl
+            torch.cuda.empty_cache()
+            wl2 = Workload(a2, dev, lay2)
+            m2 = measure(a2, wl2, world, world_group, g2, 2, lay2, nrep2, dev, pkg, r2)
+            extras["replicas_x_tp2"] = {
+                "label": parallelism_label(world, nrep2, 2, lay2) + " -- replicas, not tensor parallelism over all ranks",
+                "global_batch": a2.batch * nrep2,
+                "ms_per_step": m2["dt"] / args.steps * 1e3,
+                "tokens_per_s": a2.batch * nrep2 * args.steps / m2["dt"],
+                "collectives": m2["collectives"], "launch": m2["mode"], "rccl_ranks": m2["rccl_ranks"],
+            }
+        except Exception as exc:  # a side measurement: it must not take the headline line with it
+            extras["replicas_x_tp2_error"] = repr(exc)[:300]
+        if rank == 0:
+            signal.alarm(0)
 
     if world == 1 and not args.no_extras:
         extras = {}

@@ -164,3 +164,52 @@ def test_whole_model_against_reference_logits(gpu, dt_name, rtol, atol):
                                f"{(logits.float().cpu() - want.float()).abs().max().item():.3e}"
         if dt_name == "f32":
             assert torch.equal(logits.float().cpu().argmax(-1), want.float().argmax(-1)), step["kind"]
+
+
+@pytest.mark.parametrize("dt_name,rtol,atol", [("f32", 2e-4, 2e-5), ("bf16", 6e-2, 6e-2)])
+def test_tensor_parallel_model_against_reference_logits(gpu, dt_name, rtol, atol):
+    """The same runs with the model cut over TWO ranks (threads of this process on the one GPU,
+    ``LocalGroup``): each rank holds one of the two q heads, its own copy of the single kv head in
+    its own pool, half of the MLP; ``o_proj`` and ``down_proj`` are row-parallel and summed with
+    ``tp_all_reduce_sum`` (tp_runtime.py:28-33).  Every rank's logits against the reference
+    model's (unsharded) goldens, to the tolerances of the unsharded test."""
+    import baby_sglang_amd as pkg
+
+    g = load_golden("tiny_model")
+    cfg = types.SimpleNamespace(**g["config"], tie_word_embeddings=False, hidden_act="silu", rope_scaling=None)
+    dtype, world = DT[dt_name], 2
+    group = pkg.LocalGroup(world)
+
+    def rank_body(rank):
+        layout = pkg.TPLayout(rank, world, cfg.num_attention_heads, cfg.num_key_value_heads, replicate_kv=True)
+        model = pkg.BabyQwen2ForCausalLM(cfg, tp_layout=layout, tp_group=group).eval()
+        missing = model.load_state_dict(pkg.shard_state_dict(g["state_dict"], cfg, layout), strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
+        model = model.to(dtype).to(gpu)
+        pool = g["pool"]
+        r2t = pkg.ReqToTokenPool(pool["max_req"], pool["max_ctx"], str(gpu))
+        kv = pkg.MHATokenToKVPool(pool["size"], dtype, layout.local_kv_heads, cfg.head_dim, cfg.num_hidden_layers, str(gpu))
+        kv.arena.zero_()
+        outs = []
+        for step in g["runs"][dt_name]:
+            r2t.req_to_token.copy_(step["req_to_token"])
+            common = dict(input_ids=step["input_ids"].to(gpu), req_pool_indices=step["req_pool_indices"].to(gpu),
+                          seq_lens=step["seq_lens"].to(gpu), out_cache_loc=step["out_cache_loc"].to(gpu),
+                          req_to_token_pool=r2t, token_to_kv_pool=kv)
+            if step["prefix_lens"] is None:
+                fb = pkg.SimplifiedForwardBatch.create_decode_batch(**common)
+            else:
+                fb = pkg.SimplifiedForwardBatch.create_prefill_batch(prefix_lens=step["prefix_lens"].to(gpu), **common)
+            outs.append(model(common["input_ids"], fb.positions, fb).float().cpu())
+        return outs
+
+    per_rank = group.run(rank_body)
+    for rank, outs in enumerate(per_rank):
+        for step, logits in zip(g["runs"][dt_name], outs):
+            want = step["logits"].float()
+            ok = torch.isclose(logits, want, rtol=rtol, atol=atol)
+            assert bool(ok.all()), f"rank {rank} {step['kind']}: {(~ok).sum().item()} logits off, max {(logits - want).abs().max().item():.3e}"
+            if dt_name == "f32":
+                assert torch.equal(logits.argmax(-1), want.argmax(-1)), step["kind"]
+    for a, b in zip(per_rank[0], per_rank[1]):
+        assert torch.equal(a, b)  # (the sums are taken in rank order on every rank)

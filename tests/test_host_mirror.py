@@ -1,6 +1,8 @@
 """Host-side mirror of the reference interface against traces captured from the
 reference (CPU only): allocator order, page-table writes, batch descriptors."""
 import pytest
+import types
+
 import torch
 
 from conftest import golden_names, load_golden
@@ -127,3 +129,25 @@ def test_scheduler_trace_descriptors():
                 torch.zeros(len(b["seq_lens"]), dtype=torch.int64), b["req_pool_indices"], b["seq_lens"],
                 b["out_cache_loc"], None, None)
         assert torch.equal(fb.positions, b["positions"])
+
+
+def test_shard_state_dict_shapes():
+    """Qwen2.5-1.5B head counts over 2 and 4 ranks: the cut of every projection."""
+    import baby_sglang_amd as pkg
+
+    cfg = types.SimpleNamespace(hidden_size=1536, num_attention_heads=12, num_key_value_heads=2, head_dim=128, intermediate_size=256)
+    sd = {"l.self_attn.qkv_proj.qkv_proj.weight": torch.zeros((16 * 128, 8)), "l.self_attn.qkv_proj.qkv_proj.bias": torch.arange(16 * 128.0),
+          "l.self_attn.o_proj.weight": torch.zeros((8, 12 * 128)), "l.mlp.gate_up_proj.gate_up_proj.weight": torch.zeros((512, 8)),
+          "l.mlp.down_proj.weight": torch.zeros((8, 256)), "norm.weight": torch.zeros(8)}
+    for world in (2, 4):
+        for rank in range(world):
+            lay = pkg.TPLayout(rank, world, 12, 2, replicate_kv=True)
+            cut = pkg.shard_state_dict(sd, cfg, lay)
+            hq_l = 12 // world
+            assert cut["l.self_attn.qkv_proj.qkv_proj.weight"].shape == ((hq_l + 2) * 128, 8)
+            assert cut["l.self_attn.o_proj.weight"].shape == (8, hq_l * 128)
+            assert cut["l.mlp.gate_up_proj.gate_up_proj.weight"].shape == (512 // world, 8)
+            assert cut["l.mlp.down_proj.weight"].shape == (8, 256 // world)
+            b = cut["l.self_attn.qkv_proj.qkv_proj.bias"]
+            kv_head = rank * 2 // world
+            assert b[0].item() == rank * hq_l * 128 and b[hq_l * 128].item() == (12 + kv_head) * 128 and b[(hq_l + 1) * 128].item() == (14 + kv_head) * 128
