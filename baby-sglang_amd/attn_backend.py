@@ -23,6 +23,8 @@ Behaviour kept from the reference, deliberately:
 
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _hip
@@ -39,6 +41,12 @@ class SimpleAttentionBackend:
     # request's page-table row names (scheduler.py:459-490); set to False to
     # keep the write a launch of its own.
     fuse_decode_kv_write = True
+    # Debug aid for that assumption (BABYSGL_CHECK_FUSED_KV=1, or set the attribute): before every
+    # decode call that fuses the write, check on the device -- with a host read, so not for
+    # production -- that no slot in out_cache_loc is named by ANOTHER request's visible page-table
+    # entries (or twice in out_cache_loc); a caller that breaks the rule gets a ValueError
+    # instead of silently wrong numbers.
+    check_fused_kv_invariant = os.getenv("BABYSGL_CHECK_FUSED_KV", "0") not in ("", "0")
     # one zero-initialised decode workspace per (device, stream): calls on
     # different streams may overlap (overlap_worker.py:104-127) and must not
     # share split-merge tickets
@@ -93,12 +101,35 @@ class SimpleAttentionBackend:
         return n_splits, ws, (need, stream)
 
     @staticmethod
+    def _check_fused_kv(forward_batch: SimplifiedForwardBatch) -> None:
+        table = forward_batch.req_to_token_pool.req_to_token
+        rows = forward_batch.req_pool_indices.long()
+        seq = forward_batch.seq_lens.long()
+        loc = forward_batch.out_cache_loc.long()
+        width = int(seq.max().item()) if seq.numel() else 0
+        visible = table[rows, :width].long()  # [B, width]
+        live = torch.arange(width, device=table.device)[None, :] < seq[:, None]
+        # hits[i, j]: request j's visible entries name request i's new slot
+        hits = ((visible[None, :, :] == loc[:, None, None]) & live[None, :, :]).any(dim=-1)
+        hits.fill_diagonal_(False)
+        dup = loc.numel() != loc.unique().numel()
+        if dup or bool(hits.any().item()):
+            bad = hits.nonzero()[:4].tolist()
+            raise ValueError(
+                "fuse_decode_kv_write: a slot in out_cache_loc is named by another request's page-table row "
+                f"(new slot of request i, named by request j: {bad}; duplicate slots: {dup}); set "
+                "SimpleAttentionBackend.fuse_decode_kv_write = False for such batches"
+            )
+
+    @staticmethod
     def _decode_attention(q, k, v, forward_batch: SimplifiedForwardBatch, layer_id: int):
         pool = forward_batch.token_to_kv_pool
         if pool.store_dtype != pool.dtype:
             raise NotImplementedError("float8 KV cache write is not supported in baby-sglang MVP")
         k_slab, v_slab = pool.get_kv_buffer(layer_id)
         table = forward_batch.req_to_token_pool.req_to_token
+        if k is not None and SimpleAttentionBackend.fuse_decode_kv_write and SimpleAttentionBackend.check_fused_kv_invariant:
+            SimpleAttentionBackend._check_fused_kv(forward_batch)
         n_splits, ws, plan = SimpleAttentionBackend._decode_workspace(q, q.shape[1], k_slab.shape[1], table.shape[1])
         return _hip.paged_decode(
             q,
