@@ -46,6 +46,24 @@ _vp, _i64, _i32, _f32, _sz = (
     ctypes.c_float,
     ctypes.c_size_t,
 )
+class DecodeCall(ctypes.Structure):
+    """``bsgl_decode_call`` of include/bsgl_attn.h: the arguments of ``bsgl_paged_decode`` as one
+    struct, so that a caller fills the fields that never change once and passes one pointer."""
+
+    _fields_ = [
+        ("out", _vp), ("out_row_stride", _i64), ("lse", _vp),
+        ("q", _vp), ("q_row_stride", _i64),
+        ("k_new", _vp), ("v_new", _vp), ("k_new_row_stride", _i64), ("v_new_row_stride", _i64),
+        ("out_cache_loc", _vp),
+        ("k_slab", _vp), ("v_slab", _vp), ("slab_row_stride", _i64), ("n_slots", _i64),
+        ("req_to_token", _vp), ("table_row_stride", _i64), ("table_rows", _i64), ("table_cols", _i64),
+        ("req_pool_indices", _vp), ("seq_lens", _vp),
+        ("batch", _i32), ("n_q_heads", _i32), ("n_kv_heads", _i32), ("head_dim", _i32),
+        ("scale", _f32), ("dtype", _i32), ("out_dtype", _i32), ("n_splits", _i32), ("variant", _i32), ("reserved", _i32),
+        ("workspace", _vp), ("workspace_bytes", _sz), ("stream", _vp),
+    ]  # fmt: skip
+
+
 SIGNATURES = {
     "bsgl_abi_version": (ctypes.c_int, []),
     "bsgl_last_error": (ctypes.c_char_p, []),
@@ -65,6 +83,7 @@ SIGNATURES = {
         + [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp]
         + [_i32, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _i32, _vp, _sz, _vp],
     ),
+    "bsgl_paged_decode_call": (ctypes.c_int, [ctypes.POINTER(DecodeCall)]),
     "bsgl_paged_decode_static": (
         ctypes.c_int,
         [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _vp]
@@ -153,6 +172,19 @@ def _need_gpu(*tensors: torch.Tensor) -> None:
 
 def _stream_ptr(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
+
+
+try:  # the raw handle without building a torch.cuda.Stream object (a third of the cost)
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:  # pragma: no cover  (older / newer torch without the private hook)
+    _raw_stream = None
+
+
+def current_stream_handle(device_index: int) -> int:
+    """hipStream_t of the caller's current stream on ``device_index`` as an int."""
+    if _raw_stream is not None:
+        return _raw_stream(device_index)
+    return torch.cuda.current_stream(device_index).cuda_stream
 
 
 def _rows(x: torch.Tensor) -> torch.Tensor:

@@ -24,6 +24,7 @@ Behaviour kept from the reference, deliberately:
 from __future__ import annotations
 
 import os
+import threading
 
 import torch
 
@@ -121,15 +122,118 @@ class SimpleAttentionBackend:
                 "SimpleAttentionBackend.fuse_decode_kv_write = False for such batches"
             )
 
+    # (pool, layer, batch, q heads, dtype, page table) -> a filled-in _hip.DecodeCall: everything
+    # about a layer's decode call that does not change from step to step
+    _calls = {}
+
+    @staticmethod
+    def _decode_call(q, pool, table, layer_id: int):
+        """The call descriptor of this (layer, batch shape): slabs, page table, head counts,
+        splits and variant filled in once."""
+        batch, hq, dim = q.shape
+        # (one descriptor per calling thread: a worker thread and the main thread never fill the same struct)
+        key = (id(pool), layer_id, batch, hq, q.dtype, table.data_ptr(), threading.get_ident())
+        hit = SimpleAttentionBackend._calls.get(key)
+        if hit is not None and hit[1] is pool and hit[2] is table:
+            return hit[0]
+        if pool.store_dtype != pool.dtype:
+            return None
+        k_slab, v_slab = pool.get_kv_buffer(layer_id)
+        if k_slab.dtype != q.dtype or k_slab.stride(0) != v_slab.stride(0) or k_slab.shape[2] != dim:
+            return None
+        if table.dtype != torch.int32 or table.stride(1) != 1:
+            return None
+        hkv = k_slab.shape[1]
+        n_splits = _hip.decode_num_splits(batch, hkv, table.shape[1])
+        c = _hip.DecodeCall()
+        c.out_row_stride = hq * dim
+        c.q_row_stride = hq * dim
+        c.k_slab, c.v_slab = k_slab.data_ptr(), v_slab.data_ptr()
+        c.slab_row_stride, c.n_slots = k_slab.stride(0), k_slab.shape[0]
+        c.req_to_token = table.data_ptr()
+        c.table_row_stride, c.table_rows, c.table_cols = table.stride(0), table.shape[0], table.shape[1]
+        c.batch, c.n_q_heads, c.n_kv_heads, c.head_dim = batch, hq, hkv, dim
+        c.scale = dim**-0.5
+        c.dtype = c.out_dtype = _hip._DTYPE_CODE[q.dtype]
+        c.n_splits = n_splits
+        c.workspace_bytes = _hip.decode_workspace_bytes(batch, hq, dim, n_splits)
+        if len(SimpleAttentionBackend._calls) > 4096:
+            SimpleAttentionBackend._calls.clear()
+        SimpleAttentionBackend._calls[key] = (c, pool, table, _hip.ctypes.byref(c))
+        return c
+
+    @staticmethod
+    def _decode_fast(q, k, v, forward_batch: SimplifiedForwardBatch, layer_id: int):
+        """One foreign call per layer: the descriptor of `_decode_call` with the step's pointers
+        put in.  Returns None when the call is not of the plain shape (the general wrapper then
+        takes it): q dense, int64 index arrays, int32 slots, new rows in q's dtype."""
+        pool = forward_batch.token_to_kv_pool
+        table = forward_batch.req_to_token_pool.req_to_token
+        if not q.is_cuda or not q.is_contiguous() or q.dim() != 3 or q.dtype not in _hip._DTYPE_CODE:
+            return None
+        c = SimpleAttentionBackend._decode_call(q, pool, table, layer_id)
+        if c is None:
+            return None
+        # what the batch brings, looked up once per step (the same object comes back for every layer)
+        step = getattr(forward_batch, "_bsgl_step", None)
+        dev_index = q.device.index
+        stream = _hip.current_stream_handle(dev_index)
+        if step is None or step[0] != stream:
+            rows, seq, loc = forward_batch.req_pool_indices, forward_batch.seq_lens, forward_batch.out_cache_loc
+            if rows.dtype != torch.int64 or seq.dtype != torch.int64 or not rows.is_contiguous() or not seq.is_contiguous():
+                return None
+            if rows.shape[0] != c.batch or seq.shape[0] != c.batch:
+                return None
+            loc_ptr = 0
+            if loc is not None and loc.dtype == torch.int32 and loc.is_contiguous() and loc.shape[0] == c.batch:
+                loc_ptr = loc.data_ptr()
+            ws = SimpleAttentionBackend._workspaces.get((q.device, stream))
+            if ws is None or ws.numel() < c.workspace_bytes:
+                ws = _hip.new_decode_workspace(max(c.workspace_bytes, 1 << 20), q.device)
+                SimpleAttentionBackend._workspaces[(q.device, stream)] = ws
+            step = (stream, rows.data_ptr(), seq.data_ptr(), loc_ptr, ws.data_ptr(), ws)
+            try:
+                forward_batch._bsgl_step = step
+            except AttributeError:  # (a batch object that takes no new attributes)
+                pass
+        variant = SimpleAttentionBackend.decode_variant
+        if k is not None:
+            if step[3] == 0 or k.dtype != q.dtype or v.dtype != q.dtype:
+                return None
+            ks, vs, shape = k.stride(), v.stride(), k.shape
+            # ([batch, kv heads, dim] with dense rows; v is a column slice of the projection's output, qwen2.py:288)
+            if len(shape) != 3 or shape != v.shape or ks[1:] != (shape[2], 1) or vs[1:] != (shape[2], 1) \
+                    or shape[0] != c.batch or shape[1] != c.n_kv_heads or shape[2] != c.head_dim:
+                return None
+            c.k_new, c.v_new, c.k_new_row_stride, c.v_new_row_stride = k.data_ptr(), v.data_ptr(), ks[0], vs[0]
+            c.out_cache_loc = step[3]
+            if SimpleAttentionBackend.fuse_decode_kv_write:
+                variant |= _hip.DECODE_FUSE_KV_WRITE
+        else:
+            c.k_new = c.v_new = c.out_cache_loc = None
+        out = torch.empty((c.batch, c.n_q_heads * c.head_dim), dtype=q.dtype, device=q.device)
+        c.out, c.q = out.data_ptr(), q.data_ptr()
+        c.req_pool_indices, c.seq_lens = step[1], step[2]
+        c.variant = variant
+        c.workspace = step[4] if c.workspace_bytes else None
+        c.stream = stream
+        rc = _hip.lib.bsgl_paged_decode_call(c)
+        if rc:
+            _hip._check(rc, "bsgl_paged_decode_call")
+        return out
+
     @staticmethod
     def _decode_attention(q, k, v, forward_batch: SimplifiedForwardBatch, layer_id: int):
+        if k is not None and SimpleAttentionBackend.fuse_decode_kv_write and SimpleAttentionBackend.check_fused_kv_invariant:
+            SimpleAttentionBackend._check_fused_kv(forward_batch)
+        out = SimpleAttentionBackend._decode_fast(q, k, v, forward_batch, layer_id)
+        if out is not None:
+            return out
         pool = forward_batch.token_to_kv_pool
         if pool.store_dtype != pool.dtype:
             raise NotImplementedError("float8 KV cache write is not supported in baby-sglang MVP")
         k_slab, v_slab = pool.get_kv_buffer(layer_id)
         table = forward_batch.req_to_token_pool.req_to_token
-        if k is not None and SimpleAttentionBackend.fuse_decode_kv_write and SimpleAttentionBackend.check_fused_kv_invariant:
-            SimpleAttentionBackend._check_fused_kv(forward_batch)
         n_splits, ws, plan = SimpleAttentionBackend._decode_workspace(q, q.shape[1], k_slab.shape[1], table.shape[1])
         return _hip.paged_decode(
             q,

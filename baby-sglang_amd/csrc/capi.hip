@@ -421,6 +421,15 @@ int bsgl_paged_decode(void* out, int64_t out_row_stride, float* lse, const void*
                       scale, dtype, out_dtype, n_splits, variant, workspace, workspace_bytes, false, stream);
 }
 
+int bsgl_paged_decode_call(const bsgl_decode_call* c) {
+  if (c == nullptr) return fail(BSGL_ERR_BAD_ARG, "null call descriptor");
+  return decode_entry(c->out, c->out_row_stride, c->lse, c->q, c->q_row_stride, c->k_new, c->v_new, c->k_new_row_stride,
+                      c->v_new_row_stride, c->out_cache_loc, c->k_slab, c->v_slab, c->slab_row_stride, c->n_slots,
+                      c->req_to_token, c->table_row_stride, c->table_rows, c->table_cols, c->req_pool_indices, c->seq_lens,
+                      c->batch, c->n_q_heads, c->n_kv_heads, c->head_dim, c->scale, c->dtype, c->out_dtype, c->n_splits,
+                      c->variant, c->workspace, c->workspace_bytes, false, c->stream);
+}
+
 int bsgl_paged_decode_static(void* out, int64_t out_row_stride, float* lse, const void* q, int64_t q_row_stride,
                              const void* k_new, const void* v_new, int64_t k_new_row_stride, int64_t v_new_row_stride,
                              const int32_t* out_cache_loc,

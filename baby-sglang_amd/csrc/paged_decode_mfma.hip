@@ -580,7 +580,9 @@ void decode_mfma_kernel(DecodeArgs a) {
 #ifdef BSGL_CUT_AFTER_PARTIALS
   return;  // timing experiment (tools/phase_cut.sh; results are wrong): no ticket, no merge
 #endif
+#ifndef BSGL_CUT_NO_DRAIN  // (timing experiment, tools/phase_cut.sh: results may be wrong without the wait)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every partial byte of this wave has left
+#endif
   uint32_t* counter = a.counters + (int64_t)row * n_hg + hg;
   uint32_t ticket = 0;
   if (lane == 0) ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

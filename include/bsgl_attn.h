@@ -158,6 +158,51 @@ int bsgl_paged_decode(void* out /*device*/, int64_t out_row_stride,
                       void* workspace /*device*/, size_t workspace_bytes, void* stream);
 
 /*
+ * bsgl_paged_decode with its arguments in a struct (same meaning, same checks, same launch).
+ * Stands behind the same reference call (attn_backend.py:112-149).  For host languages in which
+ * every argument of a foreign call is converted one by one (Python's ctypes): a caller that
+ * decodes layer after layer keeps one bsgl_decode_call per (layer, batch shape), fills the fields
+ * that never change once (slabs, page table, head counts, splits, workspace) and per call only
+ * the few that do (q, out, the new rows, the batch's index arrays, the stream).
+ */
+typedef struct bsgl_decode_call {
+  void* out;
+  int64_t out_row_stride;
+  float* lse;
+  const void* q;
+  int64_t q_row_stride;
+  const void* k_new;
+  const void* v_new;
+  int64_t k_new_row_stride;
+  int64_t v_new_row_stride;
+  const int32_t* out_cache_loc;
+  void* k_slab;
+  void* v_slab;
+  int64_t slab_row_stride;
+  int64_t n_slots;
+  const int32_t* req_to_token;
+  int64_t table_row_stride;
+  int64_t table_rows;
+  int64_t table_cols;
+  const int64_t* req_pool_indices;
+  const int64_t* seq_lens;
+  int32_t batch;
+  int32_t n_q_heads;
+  int32_t n_kv_heads;
+  int32_t head_dim;
+  float scale;
+  int32_t dtype;
+  int32_t out_dtype;
+  int32_t n_splits;
+  int32_t variant;
+  int32_t reserved; /* 0 */
+  void* workspace;
+  size_t workspace_bytes;
+  void* stream;
+} bsgl_decode_call;
+int bsgl_paged_decode_call(const bsgl_decode_call* call);
+
+/*
  * bsgl_paged_decode without a caller workspace and without any allocation.  No counterpart in
  * the reference: it is for callers that cannot allocate device memory -- code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc -- and that have no workspace

@@ -12,7 +12,7 @@ trap 'cp /tmp/bsgl_whole.so "$lib"' EXIT
 B="python -u bench.py --steps 40 --warmup 5 --no-extras --cpu-seconds 0"
 run() { timeout -k 10 120 $B | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('  ms/step', round(d['ms_per_step'], 4), ' us/launch', round(d['roofline']['avg_launch_us'], 2))" || exit 1; }
 echo "whole kernel"; run
-for cut in AFTER_STREAM AFTER_PARTIALS; do
+for cut in ${CUTS:-AFTER_STREAM AFTER_PARTIALS NO_DRAIN}; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -fno-gpu-rdc -DBSGL_CUT_$cut -c $csrc/paged_decode_mfma.hip -o /tmp/bsgl_cut.o || exit 1
   objs=$(ls $csrc/*.o | grep -v "paged_decode_mfma.o\|gfx950")
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$lib" $objs /tmp/bsgl_cut.o -ldl || exit 1

@@ -40,8 +40,9 @@ def main():
     torch.cuda.synchronize()
     print(f"_hip.paged_decode directly: {(t1 - t0) / 20 / args.layers * 1e6:.1f} us of host time per layer call")
     # the wrapper alone: the library call replaced by a Python no-op
-    real = pkg._hip.lib.bsgl_paged_decode
+    real, real_call = pkg._hip.lib.bsgl_paged_decode, pkg._hip.lib.bsgl_paged_decode_call
     pkg._hip.lib.bsgl_paged_decode = lambda *a: 0
+    pkg._hip.lib.bsgl_paged_decode_call = lambda *a: 0
     t0 = time.perf_counter()
     for _ in range(20):
         wl.step()
@@ -49,7 +50,7 @@ def main():
     for _ in range(20):
         wl.backend_step()
     t2 = time.perf_counter()
-    pkg._hip.lib.bsgl_paged_decode = real
+    pkg._hip.lib.bsgl_paged_decode, pkg._hip.lib.bsgl_paged_decode_call = real, real_call
     print(f"without the library call: paged_decode wrapper {(t1 - t0) / 20 / args.layers * 1e6:.1f} us, backend.forward {(t2 - t1) / 20 / args.layers * 1e6:.1f} us per layer call")
     prof = cProfile.Profile()
     prof.enable()
