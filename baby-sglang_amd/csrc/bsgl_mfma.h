@@ -102,6 +102,23 @@ __device__ __forceinline__ void dma_1k(const void* gsrc, uint32_t lds_dst) {
   }
 }
 
+// The 4-byte form: 64 lanes x 4 B from per-lane global addresses to LDS bytes
+// [lds_dst, lds_dst + 256).  No register receives anything, so nothing the compiler does with
+// registers can touch data that is still on its way (an asm load INTO a register is taken to be
+// complete where the statement ends, and a copy of that register may be made before the data lands).
+__device__ __forceinline__ void dma_256(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dword %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
 // max / sum over the four lanes {l, l^16, l^32, l^48} (the lane groups that share a
 // q head), every lane receiving the result: two half exchanges on the vector ALU.
 // v_permlane32_swap a, b: lanes 32-63 of a trade places with lanes 0-31 of b;

@@ -46,7 +46,7 @@ constexpr KnobDef kKnobDefs[kKnobCount] = {
     {"BSGL_DECODE_TARGET_WGS", 1024}, {"BSGL_DECODE_MIN_CHUNK", 128}, {"BSGL_PREFILL_BLK", 0},
     {"BSGL_PREFILL_GROUP", 0},    {"BSGL_MFMA_NT", 1},             {"BSGL_MFMA_STAGES", 2},
     {"BSGL_MFMA_HPT", 1},         {"BSGL_MFMA_WAVES", 0},          {"BSGL_PREFILL_RT", 0},
-    {"BSGL_PREFILL_16", 0},       {"BSGL_PREFILL_LDS_PAD", 0},     {"BSGL_DECODE_STEAL", 0},
+    {"BSGL_PREFILL_16", 0},       {"BSGL_PREFILL_LDS_PAD", 0},
 };
 std::atomic<int> g_knobs[kKnobCount];
 std::once_flag g_knobs_once;

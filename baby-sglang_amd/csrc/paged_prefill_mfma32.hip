@@ -228,7 +228,11 @@ void prefill_mfma32_kernel(PrefillArgs a) {
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);  // retire every compiler-visible load before the step loop
   __syncthreads();
-  uint32_t ent0 = 0, ent1 = 0;  // entries of the next block on their way (asm loads, awaited by the step waits)
+  // (the entries of block b + 1 come in by LDS-DMA, raw, and are turned into row offsets in place by
+  // the threads whose wave brought them: no register ever holds data that is still on its way --
+  // an asm load INTO a register counts as complete where its statement ends, and under register
+  // pressure the compiler may copy that register before the data lands)
+  const uint32_t lds_slots = lds_ring + BUF;
 
   // a step is loaded by all waves together: wave w issues instructions w*DPW .. w*DPW+DPW-1;
   // instruction i brings tokens 2i, 2i+1 of the step (tile i / 8)
@@ -308,10 +312,11 @@ void prefill_mfma32_kernel(PrefillArgs a) {
         else dma_wait<DPW>();
         t1 = PROF ? __builtin_readcyclecounter() : 0;
         if (in_blk == 4 && more_entries) {
-          asm volatile("" : "+v"(ent0), "+v"(ent1));  // (not to be read before the wait above)
+          // (this wave's own two pieces, landed by the wait above; the barrier below publishes them)
           int32_t* half = s_slots + (((step >> 4) + 1) & 1) * SLOTS;
-          half[tid] = entry_off(ent0);
-          half[tid + 256] = entry_off(ent1);
+          const uint32_t e0 = (uint32_t)half[tid], e1 = (uint32_t)half[tid + 256];
+          half[tid] = entry_off(e0);
+          half[tid + 256] = entry_off(e1);
         }
         // ... and so has everybody's; all waves are also done reading step - 1
         __syncthreads();
@@ -320,8 +325,9 @@ void prefill_mfma32_kernel(PrefillArgs a) {
         if (step + 4 < n_steps) read_offsets(step + 4);
         if (in_blk == 2 && more_entries) {
           const int e = ((step >> 4) + 1) * SLOTS + tid;
-          asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off"
-                       : "=&v"(ent0), "=&v"(ent1) : "v"(entry_ptr(e)), "v"(entry_ptr(e + 256)) : "memory");
+          const uint32_t half = lds_slots + (uint32_t)((((step >> 4) + 1) & 1) * SLOTS * 4) + (uint32_t)wave * 256u;
+          dma_256((const void*)entry_ptr(e), __builtin_amdgcn_readfirstlane(half));
+          dma_256((const void*)entry_ptr(e + 256), __builtin_amdgcn_readfirstlane(half + 1024u));
         }
       }
       const uint64_t t3 = PROF ? __builtin_readcyclecounter() : 0;

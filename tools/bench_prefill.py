@@ -27,9 +27,13 @@ def main():
     ap.add_argument("--table", default="perm")
     ap.add_argument("--dtype", choices=["bf16", "f16"], default="bf16")
     ap.add_argument("--profile", action="store_true", help="per-phase cycle counts of the matrix-core kernel")
+    ap.add_argument("--knob", action="append", default=[], help="NAME=VALUE: set one of the library's tuning knobs, e.g. BSGL_PREFILL_BLK=64")
     a = ap.parse_args()
     import baby_sglang_amd as pkg
 
+    for kv_ in a.knob:
+        name, value = kv_.split("=")
+        pkg._hip.set_knob(name, int(value))
     dev = torch.device("cuda:0")
     dim, dtype = a.dim, torch.bfloat16 if a.dtype == "bf16" else torch.float16
     seq = a.prefix + a.ext
