@@ -49,7 +49,8 @@ using namespace mfma;
 // Register budget: 512 / waves-per-SIMD.  Two heads per workgroup fit two waves per
 // SIMD (256 registers), one head three; four heads need the whole file.  (The
 // single-wave kernel is limited by its private ring in LDS, not by registers.)
-template <typename Tag, int RT, int WAVES>
+// PROF: the build with cycle stamps (see paged_prefill_mfma32.hip for why it is a build of its own)
+template <typename Tag, int RT, int WAVES, bool PROF>
 __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES == 1 || RT > 2 ? 1 : RT == 1 ? 3 : 2)))
 void prefill_mfma_kernel(PrefillArgs a) {
   using E = Elem<Tag>;
@@ -73,7 +74,7 @@ void prefill_mfma_kernel(PrefillArgs a) {
   const uint32_t lds_ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
   const int tid = threadIdx.x;
-  const uint64_t t_entry = a.prof != nullptr ? __builtin_readcyclecounter() : 0;
+  const uint64_t t_entry = PROF ? __builtin_readcyclecounter() : 0;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lq = lane & 15;  // query position inside the wave's 16 (column of S^T, row of O)
@@ -184,7 +185,6 @@ void prefill_mfma_kernel(PrefillArgs a) {
 
   // tuning aid: cycles this wave spent waiting for its DMA, at the barrier, issuing DMA, in
   // the score / softmax half and in the PV half of its steps, and the step count
-  const bool PROF = a.prof != nullptr;
   uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   float m_run[RT], neg_mc[RT];  // reference score of the lane's row, and -(that) * scale * log2(e)
   constexpr float kSlack = 6.f;
@@ -409,10 +409,14 @@ hipError_t launch_rt(const PrefillArgs& a, hipStream_t stream) {
   dim3 grid((unsigned)n_wg, 1, 1);
   // (8-wave workgroups of 128 positions were measured too: the barrier then costs 860 cycles a
   // step instead of 280 and the kernel is 15 % slower)
-  if (a.blk_rows == 64)
-    hipLaunchKernelGGL((prefill_mfma_kernel<Tag, RT, 4>), grid, dim3(256), 0, stream, a);
-  else
-    hipLaunchKernelGGL((prefill_mfma_kernel<Tag, RT, 1>), grid, dim3(64), 0, stream, a);
+  const bool prof = a.prof != nullptr;
+  if (a.blk_rows == 64) {
+    if (prof) hipLaunchKernelGGL((prefill_mfma_kernel<Tag, RT, 4, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((prefill_mfma_kernel<Tag, RT, 4, false>), grid, dim3(256), 0, stream, a);
+  } else {
+    if (prof) hipLaunchKernelGGL((prefill_mfma_kernel<Tag, RT, 1, true>), grid, dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL((prefill_mfma_kernel<Tag, RT, 1, false>), grid, dim3(64), 0, stream, a);
+  }
   return hipGetLastError();
 }
 

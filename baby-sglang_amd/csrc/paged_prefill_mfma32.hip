@@ -54,7 +54,10 @@ __device__ __forceinline__ constexpr int acc_row(int r, int hi) { return (r & 3)
 // workgroup).  16: for batches of short extends a wave's columns are 2 q heads x 16 positions and
 // the workgroup covers 16 positions x 8 q heads, so a kv head's K/V is streamed by ONE workgroup
 // for up to 8 q heads instead of once per pair of heads.
-template <typename Tag, int PW>
+// PROF: the build with cycle stamps (per-phase sums into a.prof).  A build of its own: where a
+// stamped and an unstamped path join, the compiler waits for the stamp's value, and that wait
+// also waits for every LDS read on its way -- in the unstamped path too.
+template <typename Tag, int PW, bool PROF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 void prefill_mfma32_kernel(PrefillArgs a) {
   using E = Elem<Tag>;
@@ -82,7 +85,6 @@ void prefill_mfma32_kernel(PrefillArgs a) {
   const uint32_t lds_ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
   const int tid = threadIdx.x;
-  const bool PROF = a.prof != nullptr;
   const uint64_t t_entry = PROF ? __builtin_readcyclecounter() : 0;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -483,16 +485,14 @@ hipError_t launch_prefill_mfma32(const PrefillArgs& a, hipStream_t stream) {
   if (n_wg > 0x7fffffffll) return hipErrorInvalidValue;
   dim3 grid((unsigned)n_wg, 1, 1);
   const unsigned pad = (unsigned)max(0, knob(kKnobPrefillLdsPad));  // tuning aid: extra LDS per workgroup, to lower the occupancy
+  auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(256), pad, stream, a); };
+  const bool prof = a.prof != nullptr;
   if (a.blk_rows == 64) {
-    if (a.dtype == kBF16)
-      hipLaunchKernelGGL((prefill_mfma32_kernel<bf16_tag, 32>), grid, dim3(256), pad, stream, a);
-    else
-      hipLaunchKernelGGL((prefill_mfma32_kernel<f16_tag, 32>), grid, dim3(256), pad, stream, a);
+    if (a.dtype == kBF16) prof ? go(prefill_mfma32_kernel<bf16_tag, 32, true>) : go(prefill_mfma32_kernel<bf16_tag, 32, false>);
+    else prof ? go(prefill_mfma32_kernel<f16_tag, 32, true>) : go(prefill_mfma32_kernel<f16_tag, 32, false>);
   } else {
-    if (a.dtype == kBF16)
-      hipLaunchKernelGGL((prefill_mfma32_kernel<bf16_tag, 16>), grid, dim3(256), pad, stream, a);
-    else
-      hipLaunchKernelGGL((prefill_mfma32_kernel<f16_tag, 16>), grid, dim3(256), pad, stream, a);
+    if (a.dtype == kBF16) prof ? go(prefill_mfma32_kernel<bf16_tag, 16, true>) : go(prefill_mfma32_kernel<bf16_tag, 16, false>);
+    else prof ? go(prefill_mfma32_kernel<f16_tag, 16, true>) : go(prefill_mfma32_kernel<f16_tag, 16, false>);
   }
   return hipGetLastError();
 }

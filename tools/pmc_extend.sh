@@ -1,5 +1,5 @@
 #!/bin/bash
-# Matrix-pipe utilisation of the extend kernel from rocprofv3 PMC counters (one pass: 6 SQ + 1 GRBM).
+# Matrix-pipe utilisation of the extend kernel from rocprofv3 PMC counters (one pass: 8 SQ + 1 GRBM).
 # Usage: bash tools/pmc_extend.sh <tag> [bench_prefill args...]
 set -u
 tag=$1; shift
@@ -7,7 +7,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
-timeout -s KILL 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$out/pmc" -- python3 "$GRAFT_REPO_ROOT/tools/bench_prefill.py" --reps 3 "$@" > "$out/bench.txt" 2> "$out/pmc.err"
+timeout -s KILL 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d "$out/pmc" -- python3 "$GRAFT_REPO_ROOT/tools/bench_prefill.py" --reps 3 "$@" > "$out/bench.txt" 2> "$out/pmc.err"
 rc=$?
 echo "pmc pass rc=$rc"
 if [ $rc -ne 0 ]; then tail -5 "$out/pmc.err"; exit $rc; fi
@@ -16,12 +16,19 @@ python3 - "$out" <<'PY'
 import csv, glob, json, os, sys
 root = sys.argv[1]
 acc = {}
+dur = {}
 for f in glob.glob(os.path.join(root, "pmc", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         if "prefill_mfma" in row.get("Kernel_Name", ""):
             acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            if "Start_Timestamp" in row and "End_Timestamp" in row:
+                dur[row.get("Dispatch_Id", len(dur))] = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
 avg = {k: sum(v) / len(v) for k, v in acc.items()}
 res = {"dispatches": len(next(iter(acc.values()))) if acc else 0, "per_dispatch": avg}
+if dur:
+    res["kernel_ns"] = sum(dur.values()) / len(dur)
+    if "GRBM_GUI_ACTIVE" in avg:
+        res["clock_ghz"] = avg["GRBM_GUI_ACTIVE"] / 8.0 / res["kernel_ns"]  # (reads high on dispatches under 0.3 ms)
 if "GRBM_GUI_ACTIVE" in avg and "SQ_VALU_MFMA_BUSY_CYCLES" in avg:
     cycles = avg["GRBM_GUI_ACTIVE"] / 8.0  # the counter is summed over the 8 XCDs
     res["kernel_cycles"] = cycles
