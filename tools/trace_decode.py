@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--kv-layout", default="interleaved")
     ap.add_argument("--shape", default="12,2,128", help="q heads, kv heads, head_dim")
+    ap.add_argument("--launches", type=int, default=1, help="> 1: also print what part of the spread of streaming ends repeats from launch to launch")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     hq, hkv, dim = (int(x) for x in args.shape.split(","))
@@ -130,6 +131,41 @@ def main():
     for c in sorted(set(pieces.tolist())):
         m = pieces == c
         print(f"  rows cut in {c}: {int(m.sum())} workgroups, stream median {loop[m].median():.2f} us, tail median {tail[m].median():.2f}")
+
+
+    if args.launches > 1:
+        # the same launch traced again and again: per-workgroup mean of the end of streaming
+        ends, starts = [], []
+        for _ in range(args.launches):
+            trace.zero_()
+            _hip.lib.bsgl_debug_decode_trace(trace.data_ptr())
+            call(0)
+            torch.cuda.synchronize()
+            _hip.lib.bsgl_debug_decode_trace(None)
+            tt = trace.cpu()
+            ok = tt[:, 1] != 0
+            base = int(tt[tt[:, 0] != 0][:, 0].min())
+            ends.append(torch.where(ok, (tt[:, 2] - base).double() / 100.0, torch.nan))
+            starts.append(torch.where(ok, (tt[:, 1] - base).double() / 100.0, torch.nan))
+        e = torch.stack(ends)  # [launches, workgroups]
+        okc = ~torch.isnan(e).any(0)
+        e = e[:, okc]
+        st = torch.stack(starts)[:, okc]
+        idx = torch.arange(trace.shape[0])[okc]
+        mean_wg = e.mean(0)
+        print(f"{args.launches} launches, {int(okc.sum())} workgroups: end of streaming: overall mean {e.mean():.2f} us; "
+              f"std of a workgroup's mean over launches {mean_wg.std():.2f} us (what repeats), "
+              f"std within a workgroup across launches {e.std(0).mean():.2f} us (what does not); "
+              f"mean of each launch's last end {e.max(1).values.mean():.2f} us")
+        for mod, name in ((8, "launch index mod 8"), (2, "launch index mod 2"), (16, "launch index mod 16")):
+            row = "  ".join(f"{k}: {mean_wg[idx % mod == k].mean():.2f}" for k in range(mod))
+            print(f"  mean end by {name}:  {row}")
+        piece_i = idx // 2
+        for k in range(8):
+            m = piece_i % 8 == k
+            print(f"  split {k} of its row: mean end {mean_wg[m].mean():.2f}, mean start of streaming {st.mean(0)[m].mean():.2f}")
+        q = torch.tensor([0.0, 0.1, 0.5, 0.9, 1.0], dtype=torch.double)
+        print("  per-workgroup mean end, quantiles 0 / 10 / 50 / 90 / 100 %: " + " ".join(f"{v:.2f}" for v in mean_wg.quantile(q).tolist()))
 
 
 if __name__ == "__main__":
