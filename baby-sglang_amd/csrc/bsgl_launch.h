@@ -86,7 +86,8 @@ struct DecodeArgs {
   int64_t k_new_stride;
   int64_t v_new_stride;
   const int32_t* new_loc;
-  // tuning aid, normally NULL: 8 x uint64 per workgroup (in launch order): start, after
+  // tuning aid, normally NULL (looked at by the one-wave-per-piece kernel in its default
+  // configuration only): 8 x uint64 per workgroup (in launch order): start, after
   // the prologue, after the streaming loop, end (100 MHz ticks), XCC id, HW id, row, piece
   uint64_t* trace;
 };

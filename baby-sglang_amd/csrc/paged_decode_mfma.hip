@@ -82,7 +82,7 @@ __device__ __forceinline__ int small_div(int x, int d) {
 // ring of its own -- a wave's tile rate is set by its 8 LDS-DMA instructions per tile, so W waves
 // stream a piece W times as fast -- and wave 0 adds up their (m, l, O) in LDS before the piece's
 // result is stored, so the number of parts the split merge sees does not grow.
-template <typename Tag, int HPT, int NSTAGE, bool NT, int W = 1>
+template <typename Tag, int HPT, int NSTAGE, bool NT, int W = 1, bool TRACE = false>
 __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(2)))
 void decode_mfma_kernel(DecodeArgs a) {
   using E = Elem<Tag>;
@@ -104,7 +104,7 @@ void decode_mfma_kernel(DecodeArgs a) {
   const uint32_t lds_ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
   uint64_t* trace = nullptr;
-  if (a.trace != nullptr && wave == 0) {
+  if (TRACE && a.trace != nullptr && wave == 0) {
     trace = a.trace + 8 * ((uint64_t)blockIdx.x + (uint64_t)gridDim.x * (blockIdx.y + (uint64_t)gridDim.y * blockIdx.z));
     uint32_t xcc, hw;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -724,7 +724,11 @@ hipError_t launch_inst(const DecodeArgs& a, hipStream_t stream) {
   dim3 grid(a.rows, a.n_kv_heads / HPT, a.n_splits);
   // flat list of length-balanced pieces: at most rows * target + rows of them
   if (a.balance_target > 0) grid = dim3((unsigned)((int64_t)a.rows * (a.balance_target + 1) * (a.n_kv_heads / HPT)), 1, 1);
-  if (knob(kKnobMfmaNT))
+  // (the per-workgroup timeline is a build of its own, kept for the default configuration only:
+  // as a run-time flag its stamps cost the untraced launches 0.1 - 0.7 %)
+  if (HPT == 1 && NSTAGE == 2 && a.trace != nullptr && knob(kKnobMfmaNT))
+    hipLaunchKernelGGL((decode_mfma_kernel<Tag, 1, 2, true, 1, true>), grid, dim3(64), 0, stream, a);
+  else if (knob(kKnobMfmaNT))
     hipLaunchKernelGGL((decode_mfma_kernel<Tag, HPT, NSTAGE, true>), grid, dim3(64), 0, stream, a);
   else
     hipLaunchKernelGGL((decode_mfma_kernel<Tag, HPT, NSTAGE, false>), grid, dim3(64), 0, stream, a);
