@@ -270,6 +270,13 @@ void prefill_mfma32_kernel(PrefillArgs a) {
   // raw scores of the step about to be consumed and of the one after it: the two trade places
   // from step to step (a copy would wait for the last score product)
   f32x16 sc_a, sc_b;
+  // largest of the lane's 16 raw scores of the step that comes next, found in the shadow of that
+  // step's predecessor's PV products (steps that need the mask look again, after masking)
+  float lmax_nx = kNegInf;
+  auto max16 = [&](const f32x16& v) {
+    float m = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
+    return fmaxf(m, fmaxf(fmaxf(fmaxf(v[8], v[9]), fmaxf(v[10], v[11])), fmaxf(fmaxf(v[12], v[13]), fmaxf(v[14], v[15]))));
+  };
   auto load_k = [&](uint4 (&kf)[8], const char* st) {
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) kf[kb] = *(const uint4*)(st + k_off[kb]);
@@ -289,6 +296,7 @@ void prefill_mfma32_kernel(PrefillArgs a) {
       uint4 kf[8];
       load_k(kf, smem);
       sc_a = scores(kf);
+      lmax_nx = max16(sc_a);
     }
   }
 
@@ -350,8 +358,7 @@ void prefill_mfma32_kernel(PrefillArgs a) {
         for (int r = 0; r < 16; ++r) sc[r] = (t0m + acc_row(r, 0) <= my_last) ? sc[r] : kNegInf;
       }
       // lazy running maximum: see paged_prefill_mfma.hip
-      float lmax = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
-      lmax = fmaxf(lmax, fmaxf(fmaxf(fmaxf(sc[8], sc[9]), fmaxf(sc[10], sc[11])), fmaxf(fmaxf(sc[12], sc[13]), fmaxf(sc[14], sc[15]))));
+      const float lmax = step_masked ? max16(sc) : lmax_nx;
       if (__any(lmax > m_run + slack_raw)) {
         float x = lmax, y = lmax;
         swap32(x, y);  // the partner lane holds the position's other 16 tokens
@@ -387,6 +394,7 @@ void prefill_mfma32_kernel(PrefillArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) sn[r] = 0.f;
       float e[16], p[16];
+      float mx0 = kNegInf, mx1 = kNegInf;
       uint32_t pw[8];  // probabilities, two to a word: words 4 kk .. 4 kk + 3 = the A operand of tile kk
       uint4 vf[4];  // V fragments travel three products ahead of their use
       e[0] = fmaf(sc[0], scale_log2e, neg_mc);
@@ -416,6 +424,12 @@ void prefill_mfma32_kernel(PrefillArgs a) {
         // (as instructions of their own, here: the compiler otherwise pairs the sums into packed adds
         // and parks them at the head of the next step)
         asm volatile("v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2" : "+v"(l_run) : "v"(p[2 * i]), "v"(p[2 * i + 1]));
+        // (the next step's scores are complete by now: their largest, two maxima per gap)
+        if (i == 2) { mx0 = fmaxf(sn[0], sn[1]); mx1 = fmaxf(sn[2], sn[3]); }
+        if (i == 3) { mx0 = fmaxf(fmaxf(sn[4], sn[5]), mx0); mx1 = fmaxf(fmaxf(sn[6], sn[7]), mx1); }
+        if (i == 4) { mx0 = fmaxf(fmaxf(sn[8], sn[9]), mx0); mx1 = fmaxf(fmaxf(sn[10], sn[11]), mx1); }
+        if (i == 5) { mx0 = fmaxf(fmaxf(sn[12], sn[13]), mx0); mx1 = fmaxf(fmaxf(sn[14], sn[15]), mx1); }
+        if (i == 6) lmax_nx = fmaxf(mx0, mx1);
         __builtin_amdgcn_sched_barrier(0);
       }
       if (PROF) prof[3] += __builtin_readcyclecounter() - t3;
