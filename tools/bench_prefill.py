@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--table", default="perm")
     ap.add_argument("--dtype", choices=["bf16", "f16"], default="bf16")
     ap.add_argument("--profile", action="store_true", help="per-phase cycle counts of the matrix-core kernel")
+    ap.add_argument("--curve", type=int, default=0, help="N: time N successive groups of 10 launches (how the rate settles under sustained load)")
     ap.add_argument("--knob", action="append", default=[], help="NAME=VALUE: set one of the library's tuning knobs, e.g. BSGL_PREFILL_BLK=64")
     a = ap.parse_args()
     import baby_sglang_amd as pkg
@@ -62,6 +63,16 @@ def main():
 
     call()
     torch.cuda.synchronize()
+    if a.curve:
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.curve + 1)]
+        evs[0].record()
+        for g in range(a.curve):
+            for _ in range(10):
+                call()
+            evs[g + 1].record()
+        torch.cuda.synchronize()
+        fl = 4.0 * a.hq * dim * (a.ext * a.prefix + a.ext * (a.ext + 1) / 2) * a.batch
+        print("TFLOP/s of successive groups of 10 launches: " + " ".join(f"{fl / (evs[g].elapsed_time(evs[g + 1]) / 10) / 1e9:.0f}" for g in range(a.curve)), flush=True)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(a.reps):

@@ -7,7 +7,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
-timeout -s KILL 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d "$out/pmc" -- python3 "$GRAFT_REPO_ROOT/tools/bench_prefill.py" --reps 3 "$@" > "$out/bench.txt" 2> "$out/pmc.err"
+timeout -s KILL 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d "$out/pmc" -- python3 "$GRAFT_REPO_ROOT/tools/bench_prefill.py" --reps 30 "$@" > "$out/bench.txt" 2> "$out/pmc.err"
 rc=$?
 echo "pmc pass rc=$rc"
 if [ $rc -ne 0 ]; then tail -5 "$out/pmc.err"; exit $rc; fi
@@ -17,12 +17,18 @@ import csv, glob, json, os, sys
 root = sys.argv[1]
 acc = {}
 dur = {}
+rows = []
 for f in glob.glob(os.path.join(root, "pmc", "**", "*counter_collection.csv"), recursive=True):
-    for row in csv.DictReader(open(f)):
-        if "prefill_mfma" in row.get("Kernel_Name", ""):
-            acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-            if "Start_Timestamp" in row and "End_Timestamp" in row:
-                dur[row.get("Dispatch_Id", len(dur))] = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+    rows += [r for r in csv.DictReader(open(f)) if "prefill_mfma" in r.get("Kernel_Name", "")]
+# (the first launches after the set-up run slower: only the second half of the dispatches is averaged)
+ids = sorted({int(r["Dispatch_Id"]) for r in rows})
+late = set(ids[len(ids) // 2:])
+for row in rows:
+    if int(row["Dispatch_Id"]) not in late:
+        continue
+    acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+    if "Start_Timestamp" in row and "End_Timestamp" in row:
+        dur[row["Dispatch_Id"]] = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
 avg = {k: sum(v) / len(v) for k, v in acc.items()}
 res = {"dispatches": len(next(iter(acc.values()))) if acc else 0, "per_dispatch": avg}
 if dur:
