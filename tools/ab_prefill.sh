@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B of two builds of the library on the extend timing, interleaved rounds in one session:
+# A/B of two builds of the library on the extend timing (sustained rate: 30 untimed launches first),
+# interleaved rounds in one session:
 #   bash tools/ab_prefill.sh <other_lib.so> [rounds]
 # Runs on the GPU box from the repo root; restores the tree's library at the end.
 set -u
@@ -13,7 +14,7 @@ for s in "${shapes[@]}"; do
   for r in $(seq $rounds); do
     for which in other tree; do
       if [ $which = other ]; then cp "$other" "$lib"; else cp /tmp/bsgl_tree.so "$lib"; fi
-      echo -n "$which: "; timeout -k 10 120 python -u tools/bench_prefill.py --reps 20 $s 2>/dev/null | grep -o "[0-9.]* ms/layer *[0-9.]* TFLOP/s" || exit 1
+      echo -n "$which: "; timeout -k 10 120 python -u tools/bench_prefill.py --warmup 30 --reps 40 $s 2>/dev/null | grep -o "[0-9.]* ms/layer *[0-9.]* TFLOP/s" || exit 1
     done
   done
 done

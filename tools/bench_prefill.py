@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--table", default="perm")
     ap.add_argument("--dtype", choices=["bf16", "f16"], default="bf16")
     ap.add_argument("--profile", action="store_true", help="per-phase cycle counts of the matrix-core kernel")
+    ap.add_argument("--warmup", type=int, default=1, help="untimed launches first (30 or more: the sustained rate; see --curve)")
     ap.add_argument("--curve", type=int, default=0, help="N: time N successive groups of 10 launches (how the rate settles under sustained load)")
     ap.add_argument("--knob", action="append", default=[], help="NAME=VALUE: set one of the library's tuning knobs, e.g. BSGL_PREFILL_BLK=64")
     a = ap.parse_args()
@@ -61,7 +62,8 @@ def main():
         return pkg._hip.paged_prefill(q, k_slab, v_slab, r2t.req_to_token, rows, seq_t, pre_t, ext_t,
                                       variant=a.variant, out=out, workspace=ws)
 
-    call()
+    for _ in range(max(1, a.warmup)):
+        call()
     torch.cuda.synchronize()
     if a.curve:
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(a.curve + 1)]
