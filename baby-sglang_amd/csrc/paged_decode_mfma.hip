@@ -133,8 +133,16 @@ void decode_mfma_kernel(DecodeArgs a) {
   };
   int len0 = 0, req0 = 0;
   if (a.balance_target > 0) {
+#ifdef BSGL_CUT_KNOWN_LEN
+    // timing experiment (tools/phase_cut.sh, CUTS=KNOWN_LEN=2048; only right for a batch of that one
+    // length on page-table rows 0, 1, ...): what a piece list handed in from outside could save at
+    // most -- no trip to memory for the batch's lengths before the first block's entries are asked for
+    len0 = lane < a.rows ? BSGL_CUT_KNOWN_LEN : 0;
+    req0 = lane;
+#else
     len0 = len_of(lane);
     req0 = req_of(lane);
+#endif
   }
   const int lq = lane & 15;   // q head (column of S^T / row of O) or d column
   const int lg = lane >> 4;   // lane group

@@ -24,5 +24,6 @@ if [ $rc -ne 0 ]; then exit $rc; fi
 
 ( cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$out/prof" -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 10 --warmup 2 --no-extras --cpu-seconds 0 --mode eager > "$GRAFT_REPO_ROOT/$out/prof_bench.json" 2> "$GRAFT_REPO_ROOT/$out/prof.err" )
 rc=$?; echo "rocprof rc=$rc"
-find "$out/prof" -name "*kernel_stats.csv" | head -1 | xargs -r head -n 12
+f=$(find "$out/prof" -name "*kernel_stats.csv" | head -1)
+if [ -n "$f" ]; then grep -E "^\"Name\"|bsgl" "$f" | cut -c1-260; fi
 exit $rc
