@@ -104,11 +104,14 @@ void decode_mfma_kernel(DecodeArgs a) {
   const uint32_t lds_ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
   uint64_t* trace = nullptr;
+  uint64_t trace_cyc0 = 0;  // (timeline build) the core-clock count where streaming starts
+  uint32_t trace_xcc = 0;
   if (TRACE && a.trace != nullptr && wave == 0) {
     trace = a.trace + 8 * ((uint64_t)blockIdx.x + (uint64_t)gridDim.x * (blockIdx.y + (uint64_t)gridDim.y * blockIdx.z));
     uint32_t xcc, hw;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    trace_xcc = xcc;
     if (lane == 0) {
       trace[0] = wall_clock64();
       trace[1] = trace[2] = trace[3] = 0;
@@ -344,6 +347,7 @@ void decode_mfma_kernel(DecodeArgs a) {
     }
   }
 
+  if (TRACE && trace != nullptr) trace_cyc0 = __builtin_readcyclecounter();
   if (trace != nullptr && lane == 0) {
     trace[1] = wall_clock64();
     trace[6] = (uint64_t)row | ((uint64_t)hg << 32);
@@ -515,7 +519,11 @@ void decode_mfma_kernel(DecodeArgs a) {
       }
     }
   }
-  if (trace != nullptr && lane == 0) trace[2] = wall_clock64();
+  if (trace != nullptr && lane == 0) {
+    trace[2] = wall_clock64();
+    // core-clock cycles of the streaming phase above the XCC id: cycles / wall time = the clock this XCD ran at
+    if (TRACE) trace[4] = (uint64_t)(trace_xcc & 0xffu) | ((__builtin_readcyclecounter() - trace_cyc0) << 8);
+  }
 #ifdef BSGL_CUT_AFTER_STREAM
   // timing experiment (tools/phase_cut.sh; results are wrong): leave after the last tile.  The
   // never-true store keeps the streaming loop alive.

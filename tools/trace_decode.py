@@ -95,10 +95,13 @@ def main():
     cu_key = xcc * 1024 + se * 64 + sh * 16 + cu
     uniq, counts = cu_key.unique(return_counts=True)
     print(f"distinct CUs used {len(uniq)}; workgroups per CU: min {int(counts.min())} median {int(counts.median())} max {int(counts.max())}")
+    cyc = (t[:, 4] >> 8)[ran].double()
+    mhz = cyc / loop  # core-clock cycles of the streaming phase per us of wall time
     for x in range(8):
         m = xcc == x
         if m.any():
-            print(f"  XCC {x}: {int(m.sum())} workgroups, stream median {loop[m].median():.2f} us, last finish {fin[ran][m].max():.2f} us")
+            print(f"  XCC {x}: {int(m.sum())} workgroups, stream median {loop[m].median():.2f} us, last finish {fin[ran][m].max():.2f} us, "
+                  f"core clock while streaming {mhz[m].median():.0f} MHz")
     # stream time against workgroups sharing the CU
     per_cu = dict(zip(uniq.tolist(), counts.tolist()))
     load = torch.tensor([per_cu[int(k)] for k in cu_key])
