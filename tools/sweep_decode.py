@@ -11,7 +11,6 @@ import argparse
 import itertools
 import os
 import sys
-import types
 
 import torch
 
