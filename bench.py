@@ -662,6 +662,19 @@ def main():
             extras.update(extend_extras(dev))
         except Exception as exc:  # a side measurement: it must not take the headline line with it
             extras["extend_error"] = repr(exc)
+        try:
+            # larger decode launches of the same kernel (the launch's fixed costs weigh less): per layer call,
+            # KV write and split merge inside, 4 layers on distinct slabs replayed from a HIP graph
+            from tools import bench_decode_shapes as shapes
+
+            del wl
+            torch.cuda.empty_cache()
+            extras["larger_decode_launches"] = {
+                f"{model} shapes, batch {b} x {s_} tokens": shapes.run(model, b, s_, 4, 10, dev)
+                for model, b, s_ in (("1.5b", 64, 8192), ("1.5b", 256, 2048), ("7b", 128, 4096))
+            }
+        except Exception as exc:
+            extras["larger_decode_launches_error"] = repr(exc)
         result["extras"] = extras
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:

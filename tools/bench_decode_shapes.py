@@ -67,6 +67,7 @@ def run(model, batch, seq, layers, reps, dev):
           f"{nbytes / us / 1e6:6.2f} TB/s = {nbytes / us / 1e6 / 8:.3f} of peak  ({batch / (us * 28) * 1e6:,.0f} tokens/s at 28 layers)", flush=True)
     del kv, graph
     torch.cuda.empty_cache()
+    return {"us_per_layer": us, "algorithmic_bytes_per_launch": nbytes, "achieved_gbs": nbytes / us / 1e3, "frac_of_hbm_peak": nbytes / us / 1e6 / 8}
 
 
 def main():
