@@ -28,12 +28,14 @@ template <> __device__ __forceinline__ float rnd<f16_tag>(float x) { return (flo
 template <> __device__ __forceinline__ float rnd<f32_tag>(float x) { return x; }
 
 // ---------------------------------------------------------------------------------- RMSNorm
-// One workgroup per row; a thread keeps up to kChunks 16-byte chunks of the row in registers
-// between the two passes (sum of squares, scale), so the row is read once.
+// One workgroup per row; a thread keeps up to CHUNKS 16-byte chunks of the row in registers
+// between the two passes (sum of squares, scale), so the row is read once.  CHUNKS = 4 serves rows
+// of up to 8192 16-bit (4096 fp32) elements, every model of the target family; 16 serves wider rows.
 constexpr int kNormThreads = 256;
 constexpr int kNormChunks = 4;
+constexpr int kNormChunksWide = 16;
 
-template <typename Tag>
+template <typename Tag, int CHUNKS>
 __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(NormArgs a) {
 #pragma clang fp contract(off)  // round where the reference rounds: no fused multiply-add
   using E = Elem<Tag>;
@@ -46,10 +48,10 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(NormArgs a) {
   char* ro_row = a.residual_out ? (char*)a.residual_out + (int64_t)row * a.hidden * E::BYTES : nullptr;
   char* o_row = (char*)a.out + (int64_t)row * a.out_row_stride * E::BYTES;
 
-  float h[kNormChunks][V];
+  float h[CHUNKS][V];
   float ss = 0.f;
 #pragma unroll
-  for (int k = 0; k < kNormChunks; ++k) {
+  for (int k = 0; k < CHUNKS; ++k) {
     const int c = tid + k * kNormThreads;
     if (c < n_chunks) {
       E::unpack(*(const uint4*)(x_row + (int64_t)c * 16), h[k]);
@@ -73,7 +75,7 @@ __global__ __launch_bounds__(kNormThreads) void rmsnorm_kernel(NormArgs a) {
   for (int w = 0; w < kNormThreads / 64; ++w) total += s_part[w];
   const float rs = 1.0f / sqrtf(total / (float)a.hidden + a.eps);
 #pragma unroll
-  for (int k = 0; k < kNormChunks; ++k) {
+  for (int k = 0; k < CHUNKS; ++k) {
     const int c = tid + k * kNormThreads;
     if (c < n_chunks) {
       float w[V], o[V];
@@ -165,15 +167,25 @@ __global__ __launch_bounds__(kRopeThreads) void rope_kv_kernel(RopeArgs a) {
 hipError_t launch_rmsnorm(const NormArgs& a, hipStream_t stream) {
   if (a.rows == 0) return hipSuccess;
   const dim3 grid(a.rows), block(kNormThreads);
+  const bool wide = a.hidden > kNormThreads * kNormChunks * (a.dtype == kF32 ? 4 : 8);
   switch (a.dtype) {
-    case kBF16: hipLaunchKernelGGL(rmsnorm_kernel<bf16_tag>, grid, block, 0, stream, a); break;
-    case kF16: hipLaunchKernelGGL(rmsnorm_kernel<f16_tag>, grid, block, 0, stream, a); break;
-    default: hipLaunchKernelGGL(rmsnorm_kernel<f32_tag>, grid, block, 0, stream, a); break;
+    case kBF16:
+      if (wide) hipLaunchKernelGGL((rmsnorm_kernel<bf16_tag, kNormChunksWide>), grid, block, 0, stream, a);
+      else hipLaunchKernelGGL((rmsnorm_kernel<bf16_tag, kNormChunks>), grid, block, 0, stream, a);
+      break;
+    case kF16:
+      if (wide) hipLaunchKernelGGL((rmsnorm_kernel<f16_tag, kNormChunksWide>), grid, block, 0, stream, a);
+      else hipLaunchKernelGGL((rmsnorm_kernel<f16_tag, kNormChunks>), grid, block, 0, stream, a);
+      break;
+    default:
+      if (wide) hipLaunchKernelGGL((rmsnorm_kernel<f32_tag, kNormChunksWide>), grid, block, 0, stream, a);
+      else hipLaunchKernelGGL((rmsnorm_kernel<f32_tag, kNormChunks>), grid, block, 0, stream, a);
+      break;
   }
   return hipGetLastError();
 }
 
-int rmsnorm_max_hidden(int dtype) { return kNormThreads * kNormChunks * (dtype == kF32 ? 4 : 8); }
+int rmsnorm_max_hidden(int dtype) { return kNormThreads * kNormChunksWide * (dtype == kF32 ? 4 : 8); }
 
 hipError_t launch_rope_kv(const RopeArgs& a, hipStream_t stream) {
   if (a.n_tok == 0) return hipSuccess;
