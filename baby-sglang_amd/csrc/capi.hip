@@ -375,10 +375,21 @@ int decode_entry(void* out, int64_t out_row_stride, float* lse, const void* q, i
                   batch, n_q_heads, n_splits, need, kStaticScratchBytes);
     if (int rc = scratch_of_current_device(&workspace)) return rc;
     workspace_bytes = kStaticScratchBytes;
-    // the array keeps the last call's contents; the tickets of this call's rows must start at zero
-    const size_t ticket_bytes = align_up((size_t)batch * (size_t)n_kv_heads * 4, 256);
-    const hipError_t em = hipMemsetAsync(workspace, 0, ticket_bytes < kCounterBytes ? ticket_bytes : kCounterBytes, (hipStream_t)stream);
-    if (em != hipSuccess) return hip_fail("hipMemsetAsync(scratch tickets)", em);
+    // The array keeps the last call's contents, and the tickets of this call's rows must start at
+    // zero.  They do after every launch that ran to its end (the workgroup that merges a row stores
+    // 0 to its ticket) and in a freshly loaded array; an eager call clears them nevertheless, so that
+    // nothing an aborted launch left behind is counted.  While the stream is being CAPTURED the
+    // clearing is left out: as a memset node it was found not to be ordered in front of the kernel
+    // node when the graph is replayed (ROCm 7.0 / 7.2: rows merged from stale partial results), and a
+    // replayed graph starts from the zeros its own last replay, or the eager warm-up call, left.
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    const hipError_t ec = hipStreamIsCapturing((hipStream_t)stream, &capturing);
+    if (ec != hipSuccess) return hip_fail("hipStreamIsCapturing", ec);
+    if (capturing == hipStreamCaptureStatusNone) {
+      const size_t ticket_bytes = align_up((size_t)batch * (size_t)n_kv_heads * 4, 256);
+      const hipError_t em = hipMemsetAsync(workspace, 0, ticket_bytes < kCounterBytes ? ticket_bytes : kCounterBytes, (hipStream_t)stream);
+      if (em != hipSuccess) return hip_fail("hipMemsetAsync(scratch tickets)", em);
+    }
   }
   if (need > 0 && (workspace == nullptr || workspace_bytes < need || !aligned16(workspace)))
     return fail(BSGL_ERR_WORKSPACE, "decode with %d splits needs a 16-byte aligned workspace of %zu bytes (got %zu)", n_splits, need, workspace ? workspace_bytes : (size_t)0);

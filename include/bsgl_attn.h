@@ -211,6 +211,10 @@ int bsgl_paged_decode_call(const bsgl_decode_call* call);
  * library's code object instead: BSGL_STATIC_SCRATCH_BYTES per GPU, held by every GPU the library
  * runs on until the process ends.  The call makes no hipMalloc / hipFree and calls no allocating
  * routine; it enqueues one hipMemsetAsync (this call's tickets) and the decode launch on `stream`.
+ * While `stream` is being captured into a HIP graph the memset is left out -- as a graph node it
+ * is not ordered in front of the launch when the graph is replayed (seen on ROCm 7.0 / 7.2) -- and
+ * the tickets are the zeros that every finished launch leaves behind (the merging workgroup
+ * resets its row's ticket); make one call outside the capture first, as a warm-up.
  * The first call on a device looks the array's address up (hipGetSymbolAddress, once per device,
  * with that device current -- the caller must have the stream's device current, as for every
  * entry point).

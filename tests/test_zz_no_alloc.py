@@ -98,3 +98,46 @@ def test_static_scratch_refuses_what_does_not_fit(gpu):
     got = _hip.paged_decode(cpu["q"].to(gpu), k_slab, v_slab, r2t.req_to_token, rows, seq, n_splits=4, out=out, static_scratch=True)
     want = orc.decode_exact(cpu["q"], cpu["k_slab"], cpu["v_slab"], cpu["req_to_token"], cpu["req_pool_indices"], cpu["seq_lens"])
     assert_close(got, want, dtype, "200 requests, 4 splits")
+
+
+def test_static_scratch_inside_a_hip_graph(gpu):
+    """What the entry point is for: a decode step captured into a HIP graph (nothing is allocated
+    while capturing) and replayed on NEW queries in the same buffers -- with unchanged queries a
+    merge from the last replay's partial rows would go unnoticed -- against the workspace entry
+    point called eagerly."""
+    from baby_sglang_amd import _hip
+
+    dtype, hq, hkv, dim = torch.bfloat16, 12, 2, 128
+    seq_lens = [700, 33, 1200, 64, 2000, 1]
+    cpu, r2t, kv = random_decode_problem(gpu, dtype, hq, hkv, dim, seq_lens, seed=11)
+    k_slab, v_slab = kv.get_kv_buffer(0)
+    k_slab.copy_(cpu["k_slab"])
+    v_slab.copy_(cpu["v_slab"])
+    rows, seq = cpu["req_pool_indices"].to(gpu), cpu["seq_lens"].to(gpu)
+    q = cpu["q"].to(gpu).clone()
+    out = torch.empty((len(seq_lens), hq * dim), dtype=dtype, device=gpu)
+    n_splits = _hip.decode_num_splits(len(seq_lens), hkv, 4096)
+
+    def call(static, out_):
+        return _hip.paged_decode(q, k_slab, v_slab, r2t.req_to_token, rows, seq, n_splits=n_splits, out=out_, static_scratch=static)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        call(True, out)  # (first use of the array on this device: its address is looked up outside the capture)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        call(True, out)
+    gen = torch.Generator().manual_seed(12)
+    for _ in range(3):
+        q.copy_(torch.randn(q.shape, generator=gen).to(dtype))
+        graph.replay()
+        torch.cuda.synchronize()
+        want = torch.empty_like(out)
+        call(False, want)
+        torch.cuda.synchronize()
+        assert torch.equal(out, want)
+        exact = orc.decode_exact(q.cpu(), cpu["k_slab"], cpu["v_slab"], cpu["req_to_token"], cpu["req_pool_indices"], cpu["seq_lens"])
+        assert_close(out, exact, dtype, "graph replay of the static-scratch call")
