@@ -123,3 +123,30 @@ def test_extend_shape_of_the_bench(gpu):
     bound = 2.0**-8 * want.abs() + 2.0**-8 * spread + 1e-4
     assert bool((err <= bound).all()), f"worst excess {(err - bound).max().item():.3e}"
     assert err.mean().item() < 1.5e-3
+
+
+def test_long_contexts(gpu):
+    """Contexts far beyond the bench's: a 40 000-token request decodes (many page-table blocks per
+    piece) and a 700-token chunk extends over a 30 000-token prefix (the extend kernel streams 60
+    page-table blocks); both against the float64 oracle."""
+    from baby_sglang_amd import _hip
+
+    dtype, hq, hkv, dim = torch.bfloat16, 12, 2, 128
+    seq_lens = [40000, 1, 30700]
+    cpu, r2t, kv = random_decode_problem(gpu, dtype, hq, hkv, dim, seq_lens, seed=77)
+    k_slab, v_slab = kv.get_kv_buffer(0)
+    rows, seq = cpu["req_pool_indices"].to(gpu), cpu["seq_lens"].to(gpu)
+    want = orc.decode_exact(cpu["q"], cpu["k_slab"], cpu["v_slab"], cpu["req_to_token"], cpu["req_pool_indices"], cpu["seq_lens"])
+    for n_splits in (None, 64, 3):
+        got = _hip.paged_decode(cpu["q"].to(gpu), k_slab, v_slab, r2t.req_to_token, rows, seq, n_splits=n_splits)
+        assert_close(got, want, dtype, f"long-context decode, n_splits {n_splits}")
+    # extend: request 2 runs its last 700 tokens over the 30 000 before them
+    pre = torch.tensor([30000], dtype=torch.int64)
+    ext = torch.tensor([700], dtype=torch.int64)
+    gen = torch.Generator().manual_seed(78)
+    q = torch.randn((700, hq, dim), generator=gen).to(dtype)
+    got = _hip.paged_prefill(q.to(gpu), k_slab, v_slab, r2t.req_to_token, rows[2:3], seq[2:3], pre.to(gpu), ext.to(gpu))
+    want = orc.prefill_exact(q, cpu["k_slab"], cpu["v_slab"], cpu["req_to_token"], cpu["req_pool_indices"][2:3],
+                             cpu["seq_lens"][2:3], pre, ext)
+    err = (got.double().cpu() - want).abs()
+    assert float(err.max()) < 2e-2 and float(err.mean()) < 1.5e-3, (float(err.max()), float(err.mean()))

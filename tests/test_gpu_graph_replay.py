@@ -117,3 +117,4 @@ def test_extend_call_replayed_on_new_inputs(gpu, dtype, hq, hkv, dim):
                                  pre.cpu(), (seq - pre).cpu())
         err = (got.double().cpu() - want).abs().max().item()
         assert err < (3e-2 if dtype == torch.bfloat16 else 4e-3), err  # (the element-wise bars are in test_gpu_parity.py)
+
