@@ -150,3 +150,42 @@ def test_long_contexts(gpu):
                              cpu["seq_lens"][2:3], pre, ext)
     err = (got.double().cpu() - want).abs()
     assert float(err.max()) < 2e-2 and float(err.mean()) < 1.5e-3, (float(err.max()), float(err.mean()))
+
+
+@pytest.mark.parametrize("dtype,hq,hkv,dim,n,hi", [(torch.bfloat16, 12, 2, 128, 1100, 200), (torch.bfloat16, 12, 2, 128, 2100, 90),
+                                                   (torch.float16, 16, 1, 128, 300, 700), (torch.bfloat16, 14, 2, 64, 1500, 120)])
+def test_batches_beyond_the_piece_search(gpu, dtype, hq, hkv, dim, n, hi):
+    """More than 1024 requests (the length-balanced piece list is built for up to 1024: above that
+    the grid falls back to equal splits per request), the widest GQA group (16 q heads on one kv
+    head) and a large folded-head batch, ragged lengths, each with the default, one and four splits."""
+    from baby_sglang_amd import _hip
+
+    g = torch.Generator().manual_seed(n)
+    seq_lens = torch.randint(1, hi, (n,), generator=g).tolist()
+    cpu, r2t, kv = random_decode_problem(gpu, dtype, hq, hkv, dim, seq_lens, seed=n)
+    k_slab, v_slab = kv.get_kv_buffer(0)
+    rows, seq = cpu["req_pool_indices"].to(gpu), cpu["seq_lens"].to(gpu)
+    want = orc.decode_exact(cpu["q"], cpu["k_slab"], cpu["v_slab"], cpu["req_to_token"], cpu["req_pool_indices"], cpu["seq_lens"])
+    for ns in (None, 1, 4):
+        got = _hip.paged_decode(cpu["q"].to(gpu), k_slab, v_slab, r2t.req_to_token, rows, seq, n_splits=ns)
+        assert_close(got, want, dtype, f"batch {n}, n_splits {ns}")
+
+
+def test_hundreds_of_short_extends(gpu):
+    """700 requests extending by 0 - 40 tokens each over ragged prefixes (the 16-position blocks with
+    the q heads on the columns, empty requests in between)."""
+    from baby_sglang_amd import _hip
+
+    dtype, hq, hkv, dim, n = torch.bfloat16, 12, 2, 128, 700
+    g = torch.Generator().manual_seed(5)
+    seq_lens = torch.randint(2, 150, (n,), generator=g).tolist()
+    cpu, r2t, kv = random_decode_problem(gpu, dtype, hq, hkv, dim, seq_lens, seed=n + 1)
+    k_slab, v_slab = kv.get_kv_buffer(0)
+    rows, seq = cpu["req_pool_indices"].to(gpu), cpu["seq_lens"].to(gpu)
+    ext = torch.tensor([int(torch.randint(0, min(s, 40) + 1, (1,), generator=g)) for s in seq_lens], dtype=torch.int64)
+    pre = cpu["seq_lens"] - ext
+    q = torch.randn((int(ext.sum()), hq, dim), generator=g).to(dtype)
+    got = _hip.paged_prefill(q.to(gpu), k_slab, v_slab, r2t.req_to_token, rows, seq, pre.to(gpu), ext.to(gpu))
+    want = orc.prefill_exact(q, cpu["k_slab"], cpu["v_slab"], cpu["req_to_token"], cpu["req_pool_indices"], cpu["seq_lens"], pre, ext)
+    err = (got.double().cpu() - want).abs()
+    assert float(err.max()) < 3e-2 and float(err.mean()) < 1.5e-3, (float(err.max()), float(err.mean()))
