@@ -1,0 +1,59 @@
+"""What callers hand the backend besides dense tensors: q, k and v as column slices of one projection
+output (the reference's qkv split, qwen2.py:285-290, leaves v -- and here also q and k -- with the row
+stride of the merged row), through SimpleAttentionBackend.forward for a decode step and for an extend
+call, against the float64 oracle with the cache rows compared bit for bit."""
+import types
+
+import pytest
+import torch
+
+from oracle import attn_oracle as orc
+from test_gpu_parity import assert_close, random_decode_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype,hq,hkv,dim", [(torch.bfloat16, 12, 2, 128), (torch.float16, 14, 2, 64), (torch.float32, 4, 4, 64)])
+def test_projection_slices_as_q_k_v(gpu, dtype, hq, hkv, dim):
+    import baby_sglang_amd as pkg
+
+    g = torch.Generator().manual_seed(hq)
+    seq_lens = [5, 700, 64, 1300, 2]
+    n = len(seq_lens)
+    cpu, r2t, kv = random_decode_problem(gpu, dtype, hq, hkv, dim, seq_lens, seed=3)
+    rows, seq = cpu["req_pool_indices"].to(gpu), cpu["seq_lens"].to(gpu)
+    layer = types.SimpleNamespace(layer_id=0, scaling=dim**-0.5)
+    k_ref, v_ref = cpu["k_slab"].clone(), cpu["v_slab"].clone()
+
+    def split(t_rows):
+        qkv = torch.randn((t_rows, (hq + 2 * hkv) * dim), generator=g).to(dtype).to(gpu)
+        q = qkv[:, : hq * dim].view(t_rows, hq, dim)
+        k = qkv[:, hq * dim : (hq + hkv) * dim].view(t_rows, hkv, dim)
+        v = qkv[:, (hq + hkv) * dim :].view(t_rows, hkv, dim)
+        assert not q.is_contiguous() and not v.is_contiguous()
+        return q, k, v
+
+    # a decode step
+    q, k, v = split(n)
+    loc = r2t.req_to_token[rows, seq - 1].contiguous()
+    fb = pkg.SimplifiedForwardBatch.create_decode_batch(torch.zeros(n, dtype=torch.int64, device=gpu), rows, seq, loc, r2t, kv)
+    out = pkg.SimpleAttentionBackend.forward(q, k, v, layer, fb)
+    orc.kv_scatter_ref(k_ref, v_ref, loc.cpu(), k.cpu(), v.cpu())
+    want = orc.decode_exact(q.cpu(), k_ref, v_ref, cpu["req_to_token"], cpu["req_pool_indices"], cpu["seq_lens"])
+    assert_close(out, want, dtype, "decode with strided q / k / v")
+    assert torch.equal(kv.k_buffer[0].cpu(), k_ref) and torch.equal(kv.v_buffer[0].cpu(), v_ref)
+
+    # an extend call over cached prefixes
+    pre = torch.tensor([0, 500, 10, 1000, 1], dtype=torch.int64)
+    ext = cpu["seq_lens"] - pre
+    loc = torch.cat([r2t.req_to_token[rows[i], int(pre[i]) : seq_lens[i]] for i in range(n)]).contiguous()
+    total = int(ext.sum())
+    q, k, v = split(total)
+    fb = pkg.SimplifiedForwardBatch.create_prefill_batch(torch.zeros(total, dtype=torch.int64, device=gpu), rows, seq, loc, r2t, kv, pre.to(gpu))
+    out = pkg.SimpleAttentionBackend.forward(q, k, v, layer, fb)
+    orc.kv_scatter_ref(k_ref, v_ref, loc.cpu(), k.cpu(), v.cpu())
+    assert torch.equal(kv.k_buffer[0].cpu(), k_ref) and torch.equal(kv.v_buffer[0].cpu(), v_ref)
+    want = orc.prefill_exact(q.cpu(), k_ref, v_ref, cpu["req_to_token"], cpu["req_pool_indices"], cpu["seq_lens"], pre, ext)
+    err = (out.double().cpu() - want).abs()
+    bound = {torch.bfloat16: 3e-2, torch.float16: 4e-3, torch.float32: 1e-4}[dtype]
+    assert float(err.max()) < bound, float(err.max())  # (the element-wise bars are in test_gpu_parity.py)
