@@ -57,3 +57,44 @@ def test_projection_slices_as_q_k_v(gpu, dtype, hq, hkv, dim):
     err = (out.double().cpu() - want).abs()
     bound = {torch.bfloat16: 3e-2, torch.float16: 4e-3, torch.float32: 1e-4}[dtype]
     assert float(err.max()) < bound, float(err.max())  # (the element-wise bars are in test_gpu_parity.py)
+
+
+def test_two_threads_on_two_streams(gpu):
+    """The reference calls its backend from a worker thread on a side stream while the main thread
+    may use another (overlap_worker.py:104-127): two threads, each on a stream of its own with a
+    batch of its own, decode at the same time through ONE backend class; every result must be its
+    own batch's (split-merge workspaces and call descriptors are kept per stream / per thread)."""
+    import threading
+
+    import baby_sglang_amd as pkg
+
+    dtype, hq, hkv, dim = torch.bfloat16, 12, 2, 128
+    layer = types.SimpleNamespace(layer_id=0, scaling=dim**-0.5)
+    jobs = []
+    for t, seq_lens in enumerate(([900, 40, 1300, 7, 512, 2000], [64, 1800, 3, 700])):
+        cpu, r2t, kv = random_decode_problem(gpu, dtype, hq, hkv, dim, seq_lens, seed=20 + t)
+        rows, seq = cpu["req_pool_indices"].to(gpu), cpu["seq_lens"].to(gpu)
+        fb = pkg.SimplifiedForwardBatch.create_decode_batch(torch.zeros(len(seq_lens), dtype=torch.int64, device=gpu), rows, seq,
+                                                            torch.zeros(len(seq_lens), dtype=torch.int32, device=gpu), r2t, kv)
+        want = orc.decode_exact(cpu["q"], cpu["k_slab"], cpu["v_slab"], cpu["req_to_token"], cpu["req_pool_indices"], cpu["seq_lens"])
+        jobs.append((cpu["q"].to(gpu), fb, want, torch.cuda.Stream()))
+    torch.cuda.synchronize()
+    errors = []
+
+    def body(q, fb, want, stream):
+        try:
+            with torch.cuda.stream(stream):
+                for _ in range(40):
+                    out = pkg.SimpleAttentionBackend.forward(q, None, None, layer, fb, save_kv_cache=False)
+                stream.synchronize()
+                assert_close(out, want, dtype, "two threads, two streams")
+        except BaseException as exc:  # noqa: BLE001  (re-raised on the main thread)
+            errors.append(exc)
+
+    threads = [threading.Thread(target=body, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
