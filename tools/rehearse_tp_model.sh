@@ -1,8 +1,7 @@
 #!/bin/bash
 # The tensor-parallel MODEL across processes on ONE GPU: <ranks> fresh processes share cuda:0, set up
 # their group with init_tp() and talk over gloo (RCCL wants one GPU per rank); every rank checks its
-# logits against the reference model's.  Started from the shell because a test process that has
-# already used the GPU may not start other programs on this pool.
+# logits against the reference model's.  tests/test_gpu_tp_procs.py runs the same two ranks under pytest.
 # Usage: bash tools/rehearse_tp_model.sh [ranks=2]
 set -u
 n=${1:-2}
