@@ -14,6 +14,7 @@ from __future__ import annotations
 import ctypes
 import math
 import os
+import struct
 from typing import Optional
 
 import torch
@@ -62,6 +63,11 @@ class DecodeCall(ctypes.Structure):
         ("scale", _f32), ("dtype", _i32), ("out_dtype", _i32), ("n_splits", _i32), ("variant", _i32), ("reserved", _i32),
         ("workspace", _vp), ("workspace_bytes", _sz), ("stream", _vp),
     ]  # fmt: skip
+
+
+# out .. out_cache_loc: the ten 8-byte fields a caller rewrites on every call, as one packed write
+DECODE_CALL_HEAD = struct.Struct("=10q")
+assert DecodeCall.out.offset == 0 and DecodeCall.out_cache_loc.offset == 72 and DecodeCall.k_slab.offset == 80
 
 
 SIGNATURES = {

@@ -135,7 +135,7 @@ class SimpleAttentionBackend:
         key = (id(pool), layer_id, batch, hq, q.dtype, table.data_ptr(), threading.get_ident())
         hit = SimpleAttentionBackend._calls.get(key)
         if hit is not None and hit[1] is pool and hit[2] is table:
-            return hit[0]
+            return hit
         if pool.store_dtype != pool.dtype:
             return None
         k_slab, v_slab = pool.get_kv_buffer(layer_id)
@@ -159,8 +159,10 @@ class SimpleAttentionBackend:
         c.workspace_bytes = _hip.decode_workspace_bytes(batch, hq, dim, n_splits)
         if len(SimpleAttentionBackend._calls) > 4096:
             SimpleAttentionBackend._calls.clear()
-        SimpleAttentionBackend._calls[key] = (c, pool, table, _hip.ctypes.byref(c))
-        return c
+        # [descriptor, pool, table, pointer to the descriptor, the step whose pointers it holds]
+        rec = [c, pool, table, _hip.ctypes.byref(c), None]
+        SimpleAttentionBackend._calls[key] = rec
+        return rec
 
     @staticmethod
     def _decode_fast(q, k, v, forward_batch: SimplifiedForwardBatch, layer_id: int):
@@ -171,13 +173,13 @@ class SimpleAttentionBackend:
         table = forward_batch.req_to_token_pool.req_to_token
         if not q.is_cuda or not q.is_contiguous() or q.dim() != 3 or q.dtype not in _hip._DTYPE_CODE:
             return None
-        c = SimpleAttentionBackend._decode_call(q, pool, table, layer_id)
-        if c is None:
+        rec = SimpleAttentionBackend._decode_call(q, pool, table, layer_id)
+        if rec is None:
             return None
+        c = rec[0]
         # what the batch brings, looked up once per step (the same object comes back for every layer)
         step = getattr(forward_batch, "_bsgl_step", None)
-        dev_index = q.device.index
-        stream = _hip.current_stream_handle(dev_index)
+        stream = _hip.current_stream_handle(q.device.index)
         if step is None or step[0] != stream:
             rows, seq, loc = forward_batch.req_pool_indices, forward_batch.seq_lens, forward_batch.out_cache_loc
             if rows.dtype != torch.int64 or seq.dtype != torch.int64 or not rows.is_contiguous() or not seq.is_contiguous():
@@ -197,6 +199,7 @@ class SimpleAttentionBackend:
             except AttributeError:  # (a batch object that takes no new attributes)
                 pass
         variant = SimpleAttentionBackend.decode_variant
+        row = c.out_row_stride
         if k is not None:
             if step[3] == 0 or k.dtype != q.dtype or v.dtype != q.dtype:
                 return None
@@ -205,19 +208,23 @@ class SimpleAttentionBackend:
             if len(shape) != 3 or shape != v.shape or ks[1:] != (shape[2], 1) or vs[1:] != (shape[2], 1) \
                     or shape[0] != c.batch or shape[1] != c.n_kv_heads or shape[2] != c.head_dim:
                 return None
-            c.k_new, c.v_new, c.k_new_row_stride, c.v_new_row_stride = k.data_ptr(), v.data_ptr(), ks[0], vs[0]
-            c.out_cache_loc = step[3]
             if SimpleAttentionBackend.fuse_decode_kv_write:
                 variant |= _hip.DECODE_FUSE_KV_WRITE
+            out = torch.empty((shape[0], row), dtype=q.dtype, device=q.device)
+            # the ten leading fields of the descriptor in one write: out, its row stride, lse, q, its
+            # row stride, the new rows with their strides, their slots
+            _hip.DECODE_CALL_HEAD.pack_into(c, 0, out.data_ptr(), row, 0, q.data_ptr(), row,
+                                            k.data_ptr(), v.data_ptr(), ks[0], vs[0], step[3])
         else:
-            c.k_new = c.v_new = c.out_cache_loc = None
-        out = torch.empty((c.batch, c.n_q_heads * c.head_dim), dtype=q.dtype, device=q.device)
-        c.out, c.q = out.data_ptr(), q.data_ptr()
-        c.req_pool_indices, c.seq_lens = step[1], step[2]
+            out = torch.empty((q.shape[0], row), dtype=q.dtype, device=q.device)
+            _hip.DECODE_CALL_HEAD.pack_into(c, 0, out.data_ptr(), row, 0, q.data_ptr(), row, 0, 0, 0, 0, 0)
+        if rec[4] is not step:
+            c.req_pool_indices, c.seq_lens = step[1], step[2]
+            c.workspace = step[4] if c.workspace_bytes else None
+            c.stream = stream
+            rec[4] = step
         c.variant = variant
-        c.workspace = step[4] if c.workspace_bytes else None
-        c.stream = stream
-        rc = _hip.lib.bsgl_paged_decode_call(c)
+        rc = _hip.lib.bsgl_paged_decode_call(rec[3])
         if rc:
             _hip._check(rc, "bsgl_paged_decode_call")
         return out

@@ -52,6 +52,41 @@ def main():
     t2 = time.perf_counter()
     pkg._hip.lib.bsgl_paged_decode, pkg._hip.lib.bsgl_paged_decode_call = real, real_call
     print(f"without the library call: paged_decode wrapper {(t1 - t0) / 20 / args.layers * 1e6:.1f} us, backend.forward {(t2 - t1) / 20 / args.layers * 1e6:.1f} us per layer call")
+    # backend.forward alone: the caller's own slicing of the projection output (v_rows) taken out of the loop
+    fwd = pkg.SimpleAttentionBackend.forward
+    calls = [(wl.q[l], wl.k[l], wl.v_rows(l), wl.layers[l]) for l in range(args.layers)]
+    for _ in range(3):
+        for a in calls:
+            fwd(*a, wl.fb)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        for a in calls:
+            fwd(*a, wl.fb)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    print(f"backend.forward with ready-made arguments: {(t1 - t0) / 20 / args.layers * 1e6:.1f} us of host time per layer call")
+
+    def each(label, fn, n=2000):
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        print(f"  {label}: {(t1 - t0) / n * 1e6:.2f} us")
+
+    q, k, v, layer = calls[0]
+    B = SimpleBackend = pkg.SimpleAttentionBackend
+    pool, table = wl.fb.token_to_kv_pool, wl.fb.req_to_token_pool.req_to_token
+    rec = B._decode_call(q, pool, table, 0)
+    each("the library call alone (descriptor as it stands)", lambda: pkg._hip.lib.bsgl_paged_decode_call(rec[3]), 560)
+    each("torch.empty of the output", lambda: torch.empty((q.shape[0], 1536), dtype=q.dtype, device=q.device))
+    each("descriptor look-up (_decode_call)", lambda: B._decode_call(q, pool, table, 0))
+    each("q checks", lambda: (q.is_cuda, q.is_contiguous(), q.dim(), q.dtype in pkg._hip._DTYPE_CODE))
+    each("current stream", lambda: pkg._hip.current_stream_handle(q.device.index))
+    each("k/v strides and shape", lambda: (k.stride(), v.stride(), k.shape, v.shape, k.dtype, v.dtype))
+    each("five data_ptr()", lambda: (q.data_ptr(), k.data_ptr(), v.data_ptr(), q.data_ptr(), q.data_ptr()))
+    each("an empty lambda", lambda: None)
     prof = cProfile.Profile()
     prof.enable()
     for _ in range(20):
