@@ -117,6 +117,11 @@ SIGNATURES = {
     "bsgl_all_reduce_sum": (ctypes.c_int, [_vp, _i64, _i32, _vp]),
     "bsgl_all_gather": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "bsgl_comm_destroy": (ctypes.c_int, []),
+    "bsgl_p2p_create": (ctypes.c_int, [_i32, _i32, ctypes.POINTER(_vp), _vp, ctypes.POINTER(_vp)]),
+    "bsgl_p2p_connect": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp)]),
+    "bsgl_p2p_all_reduce_sum": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "bsgl_p2p_status": (ctypes.c_int, [_vp, ctypes.POINTER(_i32), ctypes.POINTER(_i64)]),
+    "bsgl_p2p_destroy": (ctypes.c_int, [_vp]),
 }
 
 
@@ -594,3 +599,65 @@ def all_gather(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Ten
         raise ValueError("all_gather: out must be contiguous, of x's dtype and world times its size")
     _check(lib.bsgl_all_gather(out.data_ptr(), x.data_ptr(), x.numel(), _dtype_code(x), _stream_ptr(x.device)), "bsgl_all_gather")
     return out
+
+
+# ---- one-shot all-reduce through windows the ranks map from each other ------------------------
+
+P2P_HANDLE_BYTES = 64
+P2P_MAX_WORLD = 8
+P2P_MAX_BYTES = 1 << 20
+
+
+class P2PComm:
+    """One rank's end of the library's one-shot all-reduce (``bsgl_p2p_*``): a window of device
+    memory on the current device that the peers map -- by its IPC ``handle`` from other processes,
+    by its address ``window`` inside this one.  ``connect`` takes the peers' handles or addresses
+    in rank order; ``all_reduce_sum`` then sums a tensor of at most ``P2P_MAX_BYTES`` in place on
+    the caller's current stream (every call of a communicator on the same stream)."""
+
+    def __init__(self, rank: int, world: int):
+        comm, window = _vp(), _vp()
+        handle = ctypes.create_string_buffer(P2P_HANDLE_BYTES)
+        _check(lib.bsgl_p2p_create(rank, world, ctypes.byref(comm), handle, ctypes.byref(window)), "bsgl_p2p_create")
+        self._comm = comm
+        self.rank, self.world = rank, world
+        self.handle: bytes = handle.raw
+        self.window: int = int(window.value)
+
+    def connect(self, handles: Optional[list] = None, windows: Optional[list] = None) -> None:
+        if (handles is None) == (windows is None):
+            raise ValueError("give the peers' windows either as IPC handles or as addresses")
+        if handles is not None:
+            if len(handles) != self.world or any(len(h) != P2P_HANDLE_BYTES for h in handles):
+                raise ValueError(f"connect wants {self.world} handles of {P2P_HANDLE_BYTES} bytes")
+            _check(lib.bsgl_p2p_connect(self._comm, ctypes.c_char_p(b"".join(handles)), None), "bsgl_p2p_connect")
+        else:
+            if len(windows) != self.world:
+                raise ValueError(f"connect wants {self.world} window addresses")
+            arr = (_vp * self.world)(*[int(w) for w in windows])
+            _check(lib.bsgl_p2p_connect(self._comm, None, arr), "bsgl_p2p_connect")
+
+    def fits(self, x: torch.Tensor) -> bool:
+        """Whether ``all_reduce_sum`` takes this tensor (else the caller uses another collective)."""
+        nbytes = x.numel() * x.element_size()
+        return (x.is_cuda and x.is_contiguous() and x.dtype in _DTYPE_CODE and 0 < nbytes <= P2P_MAX_BYTES
+                and nbytes % 16 == 0 and x.data_ptr() % 16 == 0)
+
+    def all_reduce_sum(self, x: torch.Tensor) -> torch.Tensor:
+        _need_gpu(x)
+        if not x.is_contiguous():
+            raise ValueError("all_reduce_sum needs a contiguous tensor")
+        _check(lib.bsgl_p2p_all_reduce_sum(self._comm, x.data_ptr(), x.numel(), _dtype_code(x), _stream_ptr(x.device)),
+               "bsgl_p2p_all_reduce_sum")
+        return x
+
+    def status(self):
+        """``(status, completed calls)`` -- waits for the device; status 0 = good, 1 = a peer did not arrive."""
+        st, calls = _i32(0), _i64(0)
+        _check(lib.bsgl_p2p_status(self._comm, ctypes.byref(st), ctypes.byref(calls)), "bsgl_p2p_status")
+        return int(st.value), int(calls.value)
+
+    def destroy(self) -> None:
+        if self._comm is not None:
+            comm, self._comm = self._comm, None
+            _check(lib.bsgl_p2p_destroy(comm), "bsgl_p2p_destroy")

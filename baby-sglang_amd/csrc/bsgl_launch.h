@@ -32,6 +32,7 @@ enum Knob : int {
   kKnobPrefillRT,       // BSGL_PREFILL_RT: q heads per workgroup of the 16x16x32 extend kernel (0 = heuristic)
   kKnobPrefill16,       // BSGL_PREFILL_16: keep the 16x16x32 extend kernel where the 32x32x16 form applies
   kKnobPrefillLdsPad,   // BSGL_PREFILL_LDS_PAD: extra LDS bytes per extend workgroup (lowers occupancy)
+  kKnobP2PWaitMs,       // BSGL_P2P_WAIT_MS: how long a one-shot all-reduce waits for a peer (default 10000)
   kKnobCount
 };
 int knob(Knob k);

@@ -31,7 +31,7 @@ int hip_fail(const char* what, hipError_t e) {
 }  // namespace
 
 namespace bsgl {
-// error reporting for the other translation units of the C surface (comm.hip)
+// error reporting for the other translation units of the C surface (comm.hip, p2p.hip)
 int set_error(int code, const char* msg) { return fail(code, "%s", msg); }
 
 namespace {
@@ -46,7 +46,7 @@ constexpr KnobDef kKnobDefs[kKnobCount] = {
     {"BSGL_DECODE_TARGET_WGS", 1024}, {"BSGL_DECODE_MIN_CHUNK", 128}, {"BSGL_PREFILL_BLK", 0},
     {"BSGL_PREFILL_GROUP", 0},    {"BSGL_MFMA_NT", 1},             {"BSGL_MFMA_STAGES", 2},
     {"BSGL_MFMA_HPT", 1},         {"BSGL_MFMA_WAVES", 0},          {"BSGL_PREFILL_RT", 0},
-    {"BSGL_PREFILL_16", 0},       {"BSGL_PREFILL_LDS_PAD", 0},
+    {"BSGL_PREFILL_16", 0},       {"BSGL_PREFILL_LDS_PAD", 0},     {"BSGL_P2P_WAIT_MS", 10000},
 };
 std::atomic<int> g_knobs[kKnobCount];
 std::once_flag g_knobs_once;

@@ -344,6 +344,49 @@ int bsgl_all_gather(void* out /*device, world * count_per_rank*/, const void* in
                     int64_t count_per_rank, int32_t dtype, void* stream);
 int bsgl_comm_destroy(void);
 
+/*
+ * One-shot all-reduce for the small messages of the tensor-parallel boundary, without a
+ * collective library -- an alternative to bsgl_all_reduce_sum behind tp_all_reduce_sum
+ * (tp_runtime.py:27-33: the [batch, hidden] sum after a row-parallel projection, 192 KiB at
+ * 64 x 1536 bf16, far below the size at which a ring pays).  Every rank owns a window of device
+ * memory that its peers map; a call is ONE launch per rank: the rank writes its addend into its
+ * window, raises a flag, waits for the peers' flags and reads all addends straight from the peers'
+ * windows (every byte crosses a link once); all ranks add in rank order in fp32, so all get the
+ * same bits.  Up to BSGL_P2P_MAX_WORLD ranks, messages up to BSGL_P2P_MAX_BYTES, a multiple of 16
+ * bytes at a 16-byte boundary (BSGL_ERR_UNSUPPORTED otherwise: use bsgl_all_reduce_sum).
+ *
+ *   bsgl_p2p_create   on the CURRENT device: allocates the window (the one allocation; set-up,
+ *                     may wait for the device) and returns a communicator; `handle_out` (host,
+ *                     BSGL_P2P_HANDLE_BYTES, or NULL) receives the window's IPC handle for peers in
+ *                     other processes, `window_out` (or NULL) its address for peers in this process.
+ *   bsgl_p2p_connect  the peers' windows in rank order, EITHER as `handles` (world x
+ *                     BSGL_P2P_HANDLE_BYTES, host; the own entry is ignored) OR as `windows` (world
+ *                     pointers valid on this device); the other argument NULL.  How handles travel
+ *                     between the ranks is the caller's business (the launcher's store, as for
+ *                     bsgl_comm_init).
+ *   bsgl_p2p_all_reduce_sum  in place on `buf`, enqueued on `stream`, no host wait, no allocation;
+ *                     the call number lives in the window, so a captured launch can be replayed.
+ *                     All calls of a communicator on ONE stream, every rank the same sequence of
+ *                     (count, dtype).  A rank whose peer does not arrive within 10 s (knob BSGL_P2P_WAIT_MS) gives up:
+ *                     `buf` is then undefined, the communicator's status becomes 1 and every later
+ *                     call returns at once without touching `buf`.
+ *   bsgl_p2p_status   copies the status (0 = good) and the number of completed calls to the host:
+ *                     WAITS for the device; for set-up checks and tests, not for the serving loop.
+ *   bsgl_p2p_destroy  unmaps the peers' windows and frees the own one (after the peers are done).
+ */
+#define BSGL_P2P_HANDLE_BYTES 64
+#define BSGL_P2P_MAX_WORLD 8
+#define BSGL_P2P_MAX_BYTES (1 << 20)
+typedef struct bsgl_p2p_comm bsgl_p2p_comm;
+int bsgl_p2p_create(int32_t rank, int32_t world, bsgl_p2p_comm** comm_out,
+                    void* handle_out /*host, BSGL_P2P_HANDLE_BYTES, or NULL*/, void** window_out /*or NULL*/);
+int bsgl_p2p_connect(bsgl_p2p_comm* comm, const void* handles /*host, world x BSGL_P2P_HANDLE_BYTES, or NULL*/,
+                     void* const* windows /*world device pointers, or NULL*/);
+int bsgl_p2p_all_reduce_sum(bsgl_p2p_comm* comm, void* buf /*device, count elements, in place*/, int64_t count,
+                            int32_t dtype, void* stream);
+int bsgl_p2p_status(bsgl_p2p_comm* comm, int32_t* status_out /*or NULL*/, int64_t* calls_out /*or NULL*/);
+int bsgl_p2p_destroy(bsgl_p2p_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif
