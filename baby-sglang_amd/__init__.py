@@ -22,6 +22,8 @@ from .tp_runtime import (
     tp_attention_exchange,
     tp_broadcast,
     use_capi_collectives,
+    use_p2p_all_reduce,
+    release_p2p_all_reduce,
 )
 
 __all__ = [
@@ -42,4 +44,6 @@ __all__ = [
     "tp_attention_exchange",
     "tp_broadcast",
     "use_capi_collectives",
+    "use_p2p_all_reduce",
+    "release_p2p_all_reduce",
 ]

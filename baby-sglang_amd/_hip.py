@@ -623,6 +623,7 @@ class P2PComm:
         self.rank, self.world = rank, world
         self.handle: bytes = handle.raw
         self.window: int = int(window.value)
+        self._last_stream = None
 
     def connect(self, handles: Optional[list] = None, windows: Optional[list] = None) -> None:
         if (handles is None) == (windows is None):
@@ -647,7 +648,12 @@ class P2PComm:
         _need_gpu(x)
         if not x.is_contiguous():
             raise ValueError("all_reduce_sum needs a contiguous tensor")
-        _check(lib.bsgl_p2p_all_reduce_sum(self._comm, x.data_ptr(), x.numel(), _dtype_code(x), _stream_ptr(x.device)),
+        stream = torch.cuda.current_stream(x.device)
+        if self._last_stream is not None and stream != self._last_stream:
+            # the calls of a communicator run one after the other: a new stream waits for the last one
+            stream.wait_stream(self._last_stream)
+        self._last_stream = stream
+        _check(lib.bsgl_p2p_all_reduce_sum(self._comm, x.data_ptr(), x.numel(), _dtype_code(x), stream.cuda_stream),
                "bsgl_p2p_all_reduce_sum")
         return x
 

@@ -216,6 +216,93 @@ def _capi(x: torch.Tensor, tp_group) -> bool:
     return _CAPI_GROUP[1] and x.is_cuda and (tp_group is _CAPI_GROUP[0] or tp_group == _CAPI_GROUP[0])
 
 
+_P2P = [None, None]  # (the group whose small sums go through the one-shot all-reduce, its P2PComm)
+
+
+def _all_agree(ok: bool, tp_group) -> bool:
+    """True when ``ok`` holds on every rank; every rank makes this call whatever happened to it."""
+    flags = [None] * dist.get_world_size(group=tp_group)
+    dist.all_gather_object(flags, bool(ok), group=tp_group)
+    return all(flags)
+
+
+def use_p2p_all_reduce(tp_group) -> bool:
+    """Route ``tp_all_reduce_sum`` of small contiguous GPU tensors over ``tp_group`` through the
+    library's one-shot all-reduce (``bsgl_p2p_*``): one launch per call, every rank reads the
+    peers' addends straight from windows they map, no collective library underneath.  The
+    [batch, hidden] sums of a tensor-parallel model are 0.2 - 1 MB: what they cost is latency, and a
+    ring pays it once per step of the ring.  Larger or unaligned tensors keep the group's other path.
+
+    Set-up (collective; one process per rank): each rank makes its window on its current device, the
+    IPC handles travel over the group's ``torch.distributed`` store, every rank maps its peers, and a
+    probe sum is checked.  Every rank goes through the same exchanges whatever fails locally, and the
+    ranks agree on the outcome: all of them switch over (True), or none does (False)."""
+    from . import _hip
+
+    if not dist.is_initialized():
+        raise ValueError("use_p2p_all_reduce needs an initialised process group for the hand-over of the handles")
+    release_p2p_all_reduce()
+    rank, world = dist.get_rank(group=tp_group), dist.get_world_size(group=tp_group)
+    comm, why = None, None
+    if world > _hip.P2P_MAX_WORLD:
+        why = f"more than {_hip.P2P_MAX_WORLD} ranks"
+    else:
+        try:
+            comm = _hip.P2PComm(rank, world)
+        except (RuntimeError, ValueError, NotImplementedError) as exc:
+            why = str(exc)
+    handles = [None] * world
+    dist.all_gather_object(handles, comm.handle if comm is not None else None, group=tp_group)
+    ok = comm is not None and all(h is not None for h in handles)
+    if ok:
+        try:
+            comm.connect(handles=handles)
+        except (RuntimeError, ValueError, NotImplementedError) as exc:
+            ok, why = False, str(exc)
+    ok = _all_agree(ok, tp_group)
+    if ok:
+        # (every rank launches the probe or none does: a rank alone would wait for its peers in vain)
+        try:
+            probe = torch.full((4096,), float(rank + 1), dtype=torch.float32, device="cuda")
+            comm.all_reduce_sum(probe)
+            torch.cuda.synchronize()
+            ok = comm.status()[0] == 0 and bool((probe == world * (world + 1) / 2).all())
+            if not ok:
+                why = "the probe sum came out wrong or a peer did not arrive"
+        except (RuntimeError, ValueError, NotImplementedError) as exc:
+            ok, why = False, str(exc)
+        ok = _all_agree(ok, tp_group)
+    if not ok:
+        if comm is not None:
+            torch.cuda.synchronize()
+            dist.barrier(group=tp_group)  # nobody unmaps a window a peer may still read
+            comm.destroy()
+        _P2P_WHY[0] = why
+        return False
+    _P2P[0], _P2P[1] = tp_group, comm
+    _P2P_WHY[0] = None
+    return True
+
+
+_P2P_WHY = [None]  # why the last use_p2p_all_reduce on this rank did not switch over (None: it did, or a peer failed)
+
+
+def release_p2p_all_reduce() -> None:
+    """Back to the group's other all-reduce.  Collective when a communicator is live: the ranks
+    meet before any window is unmapped."""
+    comm, group = _P2P[1], _P2P[0]
+    _P2P[0], _P2P[1] = None, None
+    if comm is not None:
+        torch.cuda.synchronize()
+        dist.barrier(group=group)
+        comm.destroy()
+
+
+def _p2p(x: torch.Tensor, tp_group) -> bool:
+    comm = _P2P[1]
+    return comm is not None and (tp_group is _P2P[0] or tp_group == _P2P[0]) and comm.fits(x)
+
+
 def _world(tp_group) -> int:
     if _local(tp_group):
         return tp_group.world
@@ -232,6 +319,8 @@ def tp_all_reduce_sum(x: torch.Tensor, tp_group) -> torch.Tensor:
         total = tp_group.exchange(x, lambda xs: torch.stack([t.to(x.device) for t in xs]).sum(dim=0).to(x.dtype))
         x.copy_(total)
         return x
+    if _p2p(x, tp_group):
+        return _P2P[1].all_reduce_sum(x)
     if _capi(x, tp_group) and x.is_contiguous():
         from . import _hip
 

@@ -18,7 +18,13 @@ def pytest_configure(config):
 
 
 TP_PROCS_TEST = "test_gpu_tp_procs.py"
-TP_PROCS = {}  # filled by pytest_sessionstart: {"procs": [Popen...], "logs": [path...], "dir": tmpdir}
+# job name -> (program under tools/, ranks, extra environment)
+TP_PROC_JOBS = {
+    "tp_model": ("tp_model_procs.py", 2, {}),
+    "tp_model_one_shot": ("tp_model_procs.py", 2, {"BABYSGL_P2P_ALLREDUCE": "1"}),
+    "one_shot_all_reduce": ("p2p_procs.py", 4, {}),
+}
+TP_PROCS = {}  # filled by pytest_sessionstart: job name -> {"procs": [Popen...], "logs": [path...]}
 
 
 def _wants_tp_procs(config):
@@ -35,37 +41,37 @@ def _wants_tp_procs(config):
 def pytest_sessionstart(session):
     """The ranks of tests/test_gpu_tp_procs.py are started HERE, before any test has touched the GPU:
     a process that has initialised the GPU should not start other programs on the GPU boxes, and
-    counting devices does not initialise it.  The test itself only waits for them."""
+    counting devices does not initialise it.  The tests themselves only wait for them."""
     if not _wants_tp_procs(session.config) or torch.cuda.device_count() == 0:
         return
     import socket
     import subprocess
     import tempfile
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    world = 2
     tmp = tempfile.mkdtemp(prefix="bsgl_tp_procs_")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world),
-               LOCAL_RANK="0", BABYSGL_TP_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    TP_PROCS.update(procs=[], logs=[], dir=tmp)
-    for rank in range(world):
-        log = os.path.join(tmp, f"rank{rank}.log")
-        with open(log, "wb") as f:
-            p = subprocess.Popen(
-                [sys.executable, os.path.join(ROOT, "tools", "run_with_dump.py"), "170",
-                 os.path.join(ROOT, "tools", "tp_model_procs.py")],
-                env=dict(env, RANK=str(rank)), stdout=f, stderr=subprocess.STDOUT, cwd=ROOT)
-        TP_PROCS["procs"].append(p)
-        TP_PROCS["logs"].append(log)
+    for name, (program, world, extra) in TP_PROC_JOBS.items():
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world),
+                   LOCAL_RANK="0", BABYSGL_TP_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
+        job = TP_PROCS[name] = {"procs": [], "logs": []}
+        for rank in range(world):
+            log = os.path.join(tmp, f"{name}.rank{rank}.log")
+            with open(log, "wb") as f:
+                p = subprocess.Popen(
+                    [sys.executable, os.path.join(ROOT, "tools", "run_with_dump.py"), "170", os.path.join(ROOT, "tools", program)],
+                    env=dict(env, RANK=str(rank)), stdout=f, stderr=subprocess.STDOUT, cwd=ROOT)
+            job["procs"].append(p)
+            job["logs"].append(log)
 
 
 def pytest_sessionfinish(session, exitstatus):
-    for p in TP_PROCS.get("procs", []):
-        if p.poll() is None:
-            p.kill()
-            p.wait()
+    for job in TP_PROCS.values():
+        for p in job["procs"]:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
 
 
 def golden_names(prefix):

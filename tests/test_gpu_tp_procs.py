@@ -1,10 +1,14 @@
-"""The tensor-parallel model as two PROCESSES on the one GPU: each rank sets its group up with
-init_tp() from the torchrun-style environment (gloo as the transport: RCCL wants a GPU per rank),
-shards the reference model's weights (column-parallel qkv / gate_up, row-parallel o_proj / down_proj),
-sums the row-parallel outputs with tp_all_reduce_sum and compares its logits with the reference
-model's unsharded ones (reference: tp_runtime.py:10-33, qwen2.py:179-197).  The ranks are
-tools/tp_model_procs.py; tests/conftest.py starts them when the session starts, before this process
-has touched the GPU, and this test waits for their verdicts."""
+"""Tensor-parallel ranks as PROCESSES that share the one GPU (gloo is the store and, where nothing
+else is said, the transport: RCCL wants a GPU per rank).  The rank programs are under tools/;
+tests/conftest.py starts them when the session starts, before this process has touched the GPU, and
+the tests here wait for their exit codes and verdict lines.
+
+* tools/tp_model_procs.py, two ranks: init_tp() from the torchrun-style environment, the reference
+  model's weights sharded (column-parallel qkv / gate_up, row-parallel o_proj / down_proj), the
+  row-parallel outputs summed with tp_all_reduce_sum, logits against the reference model's unsharded
+  ones (reference: tp_runtime.py:10-33, qwen2.py:179-197) -- once with gloo's sums, once with the
+  library's one-shot all-reduce through windows mapped by IPC handles;
+* tools/p2p_procs.py, four ranks: that all-reduce by itself over dtypes and sizes, bit for bit."""
 import subprocess
 
 import pytest
@@ -14,22 +18,37 @@ from conftest import TP_PROCS
 pytestmark = pytest.mark.gpu
 
 
-def test_tp_model_as_two_processes(gpu):
-    if not TP_PROCS.get("procs"):
+def _verdicts(name):
+    job = TP_PROCS.get(name)
+    if not job:
         pytest.skip("the ranks are only started when this file (or its directory) is run with -m gpu")
     codes = []
-    for p in TP_PROCS["procs"]:
+    for p in job["procs"]:
         try:
             codes.append(p.wait(timeout=180))
         except subprocess.TimeoutExpired:
             p.kill()
             codes.append("timeout")
     logs = []
-    for path in TP_PROCS["logs"]:
+    for path in job["logs"]:
         with open(path, errors="replace") as f:
             logs.append(f.read())
     report = "\n".join(f"--- rank {r} (exit {c})\n{log[-3000:]}" for r, (c, log) in enumerate(zip(codes, logs)))
     assert codes == [0] * len(codes), report
+    return logs, report
+
+
+@pytest.mark.parametrize("job", ["tp_model", "tp_model_one_shot"])
+def test_tp_model_as_two_processes(gpu, job):
+    logs, report = _verdicts(job)
     for r, log in enumerate(logs):
         for dt in ("f32", "bf16"):
             assert f"rank {r}/{len(logs)} {dt}:" in log and "equal the reference model's logits" in log, report
+        if job == "tp_model_one_shot":
+            assert "were one-shot all-reduces through IPC windows" in log, report
+
+
+def test_one_shot_all_reduce_between_four_processes(gpu):
+    logs, report = _verdicts("one_shot_all_reduce")
+    for r, log in enumerate(logs):
+        assert f"rank {r}/{len(logs)}:" in log and "equal the rank-ordered fp32 sum bit for bit" in log, report

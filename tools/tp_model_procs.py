@@ -3,7 +3,8 @@ two of them on the one GPU): init_tp() from the torchrun-style environment, gloo
 (RCCL wants a GPU per rank), column-parallel qkv / gate_up, row-parallel o_proj / down_proj summed
 with tp_all_reduce_sum (reference: tp_runtime.py:10-33, qwen2.py:179-197).  Every rank's logits over
 the golden runs (prefill, two decode steps, an extend over a cached prefix) are compared with the
-reference model's unsharded logits, to the bars of tests/test_gpu_model_ops.py."""
+reference model's unsharded logits, to the bars of tests/test_gpu_model_ops.py.  With
+BABYSGL_P2P_ALLREDUCE=1 the sums go through the library's one-shot all-reduce instead of gloo."""
 import os
 import sys
 import types
@@ -21,6 +22,9 @@ def main():
     rank, world, group = pkg.init_tp()
     assert world > 1, "start me through tools/rehearse_tp_model.sh"
     dev = torch.device("cuda", int(os.getenv("LOCAL_RANK", "0")))
+    one_shot = os.getenv("BABYSGL_P2P_ALLREDUCE", "0") not in ("", "0")
+    if one_shot:  # the sums on the device, through windows mapped by IPC handles, instead of gloo's host sums
+        assert pkg.use_p2p_all_reduce(group), f"rank {rank}: no one-shot all-reduce: {pkg.tp_runtime._P2P_WHY[0]}"
     g = torch.load(os.path.join(ROOT, "tests", "golden", "tiny_model.pt"), weights_only=True)
     cfg = types.SimpleNamespace(**g["config"], tie_word_embeddings=False, hidden_act="silu", rope_scaling=None)
     for dt_name, (dtype, rtol, atol) in BARS.items():
@@ -51,6 +55,11 @@ def main():
             worst = max(worst, float((logits - want).abs().max()))
         print(f"rank {rank}/{world} {dt_name}: {len(g['runs'][dt_name])} runs equal the reference model's logits "
               f"(max |diff| {worst:.2e}; rtol {rtol}, atol {atol})", flush=True)
+    if one_shot:
+        status, calls = pkg.tp_runtime._P2P[1].status()
+        assert status == 0 and calls > 1, (status, calls)
+        print(f"rank {rank}/{world}: {calls} of the sums were one-shot all-reduces through IPC windows", flush=True)
+        pkg.release_p2p_all_reduce()
     torch.cuda.synchronize()
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
