@@ -134,6 +134,32 @@ def test_four_ranks_as_two_replicas_of_a_two_rank_group():
     mp.spawn(_replica_worker, args=(4, _free_port()), nprocs=4, join=True)
 
 
+def _no_gpu_worker(rank, world, port):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from baby_sglang_amd import tp_runtime as tp
+
+    _, _, group = tp.init_tp(backend="gloo")
+    # no GPU: no rank can make its window; every rank still goes through the same exchanges, all
+    # agree not to switch over, and the sums keep going through the group's own all-reduce
+    assert tp.use_p2p_all_reduce(group) is False
+    assert tp._P2P == [None, None] and tp._P2P_WHY[0]
+    x = torch.full((8,), float(rank + 1))
+    assert tp.tp_all_reduce_sum(x, group) is x and x.tolist() == [world * (world + 1) / 2] * 8
+    tp.release_p2p_all_reduce()  # (nothing live: no exchange)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_shot_all_reduce_is_declined_by_all_ranks_without_a_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("the failure path: only where no window can be made")
+    mp.spawn(_no_gpu_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
 def test_layouts():
     import sys
 
