@@ -325,6 +325,14 @@ def tp_all_reduce_sum(x: torch.Tensor, tp_group) -> torch.Tensor:
         from . import _hip
 
         return _hip.all_reduce_sum(x)
+    if x.is_cuda and dist.get_backend(tp_group) == "gloo":
+        # rehearsals of several ranks on one GPU: summed on the host, through a copy that waits for
+        # the stream (gloo's own handling of device tensors gave wrong sums here while other
+        # processes kept the GPU busy)
+        host = x.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=tp_group)
+        x.copy_(host)
+        return x
     dist.all_reduce(x, op=dist.ReduceOp.SUM, group=tp_group)
     return x
 

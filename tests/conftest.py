@@ -49,10 +49,14 @@ def pytest_sessionstart(session):
     import tempfile
 
     tmp = tempfile.mkdtemp(prefix="bsgl_tp_procs_")
-    for name, (program, world, extra) in TP_PROC_JOBS.items():
-        with socket.socket() as s:
-            s.bind(("127.0.0.1", 0))
-            port = s.getsockname()[1]
+    # one rendezvous port per job, all picked before any is given back: no two jobs get the same one
+    socks = [socket.socket() for _ in TP_PROC_JOBS]
+    for s in socks:
+        s.bind(("127.0.0.1", 0))
+    ports = [s.getsockname()[1] for s in socks]
+    for s in socks:
+        s.close()
+    for port, (name, (program, world, extra)) in zip(ports, TP_PROC_JOBS.items()):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world),
                    LOCAL_RANK="0", BABYSGL_TP_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
         job = TP_PROCS[name] = {"procs": [], "logs": []}
