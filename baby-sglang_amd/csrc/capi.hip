@@ -177,9 +177,12 @@ int run_decode(bsgl::DecodeArgs& a, int32_t variant, uint32_t* counters, hipStre
   if (a.balance_target > 0) {
     // Small batches get many splits, but pieces much shorter than 256 tokens cost more in the merge
     // than they gain (a piece can be shared by up to four waves instead): no more pieces than
-    // 512-token stretches of a full page-table row.  (Measured in a 4096-column table, 2048-token
-    // requests: 8 pieces against 16 is 7 - 15 % faster for 4 - 32 requests, 4 % slower for 1 - 2.)
-    const int64_t cap = a.kv.table_cols / 512 > 4 ? a.kv.table_cols / 512 : 4;
+    // 512-token stretches of a full page-table row -- 256-token stretches for one or two requests,
+    // which leave most of the chip idle either way.  (Measured in a 4096-column table: 8 pieces
+    // against 16 is 7 - 15 % faster for 4 - 32 requests of 2048 tokens; for one request 16 pieces are
+    // 4 % faster at 2048 tokens and 14 % at 4095.)
+    const int64_t stretch = a.rows <= 2 ? 256 : 512;
+    const int64_t cap = a.kv.table_cols / stretch > 4 ? a.kv.table_cols / stretch : 4;
     if (a.balance_target > cap) a.balance_target = (int32_t)cap;
     const int t = bsgl::knob(bsgl::kKnobDecodeTarget);  // tuning override: pieces wanted per request
     if (t > 0 && t <= a.n_splits) a.balance_target = t;

@@ -13,7 +13,7 @@ import baby_sglang_amd as pkg  # noqa: E402
 dev = torch.device("cuda:0")
 hq, hkv, dim, dtype = 12, 2, 128, torch.bfloat16
 gen = torch.Generator(device=dev).manual_seed(0)
-for batch in (1, 8):
+for batch in (1, 2, 4, 8):
     for seq in (1, 128, 2048, 4095):
         size = batch * 4096
         kv = pkg.MHATokenToKVPool(size, dtype, hkv, dim, 1, "cuda:0")
