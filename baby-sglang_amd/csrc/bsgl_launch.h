@@ -77,6 +77,9 @@ struct DecodeArgs {
   // (and no row more than n_splits); needs the in-kernel merge.  0: n_splits equal
   // pieces per row.
   int32_t balance_target;
+  // > balance_target: small batches whose requests turn out long may be cut finer, into up to this
+  // many pieces per request, as long as a piece keeps at least 256 tokens (0: no such allowance)
+  int32_t balance_target_hi;
   // matrix-core kernel, set by the host layer together with n_kv_heads = 1 and head_dim = 128 when
   // a model with two kv heads of 64 values is streamed as one 128-wide kv head: q heads per REAL kv
   // head (0 = not folded)

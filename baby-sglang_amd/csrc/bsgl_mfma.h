@@ -17,6 +17,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
 
 constexpr int kTile = 16;        // tokens per tile (= MFMA M of the score product)
+constexpr int kFinePiece = 256;  // shortest piece that DecodeArgs::balance_target_hi may cut a request into
 constexpr int kSlotBlock = 512;  // page-table entries staged in LDS at a time
 
 // qk / pv32: 16x16x32 products (8 k-values per lane); pv: the 16x16x16 form (4 per lane).

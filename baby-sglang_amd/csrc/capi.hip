@@ -172,6 +172,7 @@ int run_decode(bsgl::DecodeArgs& a, int32_t variant, uint32_t* counters, hipStre
   // length-balanced pieces: needs the in-kernel merge (a row's piece count varies) and a
   // batch small enough for every workgroup to scan its seq_lens
   a.balance_target = 0;
+  a.balance_target_hi = 0;
   if (a.counters != nullptr && a.n_splits > 1 && a.rows <= 1024 && a.kv.table_cols <= (1 << 20) && !uniform_splits && bsgl::knob(bsgl::kKnobDecodeBalance) != 0)
     a.balance_target = (a.n_splits + 1) / 2;
   if (a.balance_target > 0) {
@@ -184,8 +185,21 @@ int run_decode(bsgl::DecodeArgs& a, int32_t variant, uint32_t* counters, hipStre
     const int64_t stretch = a.rows <= 2 ? 256 : 512;
     const int64_t cap = a.kv.table_cols / stretch > 4 ? a.kv.table_cols / stretch : 4;
     if (a.balance_target > cap) a.balance_target = (int32_t)cap;
+    // A few more requests (up to 16 (request, kv head) units): whether 8 or 16 pieces are right depends
+    // on their lengths (eight requests of 2048 tokens: 8 pieces 12.1 us, 16 pieces 12.9; of 4095 tokens:
+    // 15.4 against 14.8; three requests of 4095 tokens: 14.4 against 12.6), which only the kernel sees: it
+    // may cut finer as long as a piece keeps 256 tokens.  (12 and 16 requests of two kv heads: 5 - 10 %
+    // slower that way at 3000 - 4095 tokens.)
+    if (a.rows > 2 && (int64_t)a.rows * a.n_kv_heads <= 16) {
+      const int64_t fine = a.kv.table_cols / 256;
+      const int64_t hi = fine < (a.n_splits + 1) / 2 ? fine : (a.n_splits + 1) / 2;
+      if (hi > a.balance_target) a.balance_target_hi = (int32_t)hi;
+    }
     const int t = bsgl::knob(bsgl::kKnobDecodeTarget);  // tuning override: pieces wanted per request
-    if (t > 0 && t <= a.n_splits) a.balance_target = t;
+    if (t > 0 && t <= a.n_splits) {
+      a.balance_target = t;
+      a.balance_target_hi = 0;
+    }
   }
   // (folded heads: the workgroup that merges a request reads the partial rows of ALL its q heads,
   // 14 for Qwen2.5-0.5B: more than 8 pieces per request cost more in that merge than they gain)
@@ -193,6 +207,7 @@ int run_decode(bsgl::DecodeArgs& a, int32_t variant, uint32_t* counters, hipStre
   if (a.fold_group > 0 && a.balance_target > 0) {
     const int cap = bsgl::knob(bsgl::kKnobFoldPieces);
     a.balance_target = a.n_splits < cap ? a.n_splits : cap;
+    a.balance_target_hi = 0;
   }
   const hipError_t e = use_mfma ? bsgl::launch_decode_mfma(a, stream) : bsgl::launch_decode_valu(a, stream);
   if (e != hipSuccess) return hip_fail("decode launch", e);

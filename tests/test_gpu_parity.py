@@ -356,15 +356,52 @@ def test_equal_lengths_take_the_closed_form_of_the_piece_search(gpu, length, kno
     k_slab, v_slab = kv.get_kv_buffer(0)
     q, rows, seq = cpu["q"].to(gpu), cpu["req_pool_indices"].to(gpu), cpu["seq_lens"].to(gpu)
     for n_splits in (16, 7, 2):
-        searched = _hip.paged_decode(q, k_slab, v_slab, r2t.req_to_token, rows, seq, n_splits=n_splits, variant=2)
-        assert_close(searched, want, dtype, f"65 rows of {length}, splits {n_splits}")
-        for n in (3, 9, 64):
-            closed = _hip.paged_decode(q[:n], k_slab, v_slab, r2t.req_to_token, rows[:n], seq[:n], n_splits=n_splits, variant=2)
-            assert torch.equal(closed, searched[:n]), f"{n} rows of {length}, splits {n_splits}"
-        # (one or two requests may be cut into more pieces than a larger batch: same sums, another order)
-        for n in (1, 2):
+        # (the number of pieces wanted per request pinned: small batches are otherwise allowed finer cuts)
+        old = _hip.set_knob("BSGL_DECODE_TARGET", (n_splits + 1) // 2)
+        try:
+            searched = _hip.paged_decode(q, k_slab, v_slab, r2t.req_to_token, rows, seq, n_splits=n_splits, variant=2)
+            assert_close(searched, want, dtype, f"65 rows of {length}, splits {n_splits}")
+            for n in (1, 9, 64):
+                closed = _hip.paged_decode(q[:n], k_slab, v_slab, r2t.req_to_token, rows[:n], seq[:n], n_splits=n_splits, variant=2)
+                assert torch.equal(closed, searched[:n]), f"{n} rows of {length}, splits {n_splits}"
+        finally:
+            _hip.set_knob("BSGL_DECODE_TARGET", old)
+        # the cuts a small batch gets by itself: same sums in another order
+        for n in (1, 2, 3, 8):
             closed = _hip.paged_decode(q[:n], k_slab, v_slab, r2t.req_to_token, rows[:n], seq[:n], n_splits=n_splits, variant=2)
             assert_close(closed, want[:n], dtype, f"{n} rows of {length}, splits {n_splits}")
+
+
+@pytest.mark.parametrize("seq_lens", [[4000, 300, 2500, 17, 3300], [3900, 4090, 4001], [4095] * 8, [2047] * 7 + [16],
+                                      [260, 255, 257, 3000], [4095], [4095, 1]])
+@pytest.mark.parametrize("hq,hkv", [(12, 2), (28, 4)])
+def test_small_batches_of_long_requests(gpu, seq_lens, hq, hkv):
+    """Up to sixteen (request, kv head) units: the host allows the kernel finer cuts than for a larger
+    batch (pieces of no less than 256 tokens, up to twice as many per request), decided on the device
+    from the lengths -- equal lengths in closed form, ragged ones by the search.  Against the oracle,
+    with the default number of splits for the batch and with the new token's K/V rows written by the
+    kernel."""
+    from baby_sglang_amd import _hip
+
+    dim, dtype = 128, torch.bfloat16
+    cpu, r2t, kv = random_decode_problem(gpu, dtype, hq, hkv, dim, seq_lens, seed=sum(seq_lens) + hq)
+    batch = len(seq_lens)
+    gen = torch.Generator().manual_seed(5)
+    k_new = torch.randn((batch, hkv, dim), generator=gen).to(dtype)
+    v_new = torch.randn((batch, hkv, dim), generator=gen).to(dtype)
+    loc = cpu["req_to_token"][cpu["req_pool_indices"], cpu["seq_lens"] - 1].to(torch.int32)
+    orc.kv_scatter_ref(cpu["k_slab"], cpu["v_slab"], loc, k_new, v_new)
+    want, want_lse = orc.decode_exact(cpu["q"], cpu["k_slab"], cpu["v_slab"], cpu["req_to_token"],
+                                      cpu["req_pool_indices"], cpu["seq_lens"], return_lse=True)
+    k_slab, v_slab = kv.get_kv_buffer(0)
+    n_splits = _hip.decode_num_splits(batch, hkv, r2t.req_to_token.shape[1])
+    lse = torch.empty((batch, hq), dtype=torch.float32, device=gpu)
+    out = _hip.paged_decode(cpu["q"].to(gpu), k_slab, v_slab, r2t.req_to_token, cpu["req_pool_indices"].to(gpu),
+                            cpu["seq_lens"].to(gpu), n_splits=n_splits, lse=lse, k_new=k_new.to(gpu), v_new=v_new.to(gpu),
+                            out_cache_loc=loc.to(gpu), fuse_kv_write=True)
+    assert_close(out, want, dtype, f"{seq_lens} x {hq}/{hkv}")
+    assert (lse.cpu().double() - want_lse).abs().max().item() < 2e-3
+    assert torch.equal(k_slab.cpu(), cpu["k_slab"]) and torch.equal(v_slab.cpu(), cpu["v_slab"])
 
 
 def test_decode_empty_and_zero_length(gpu):

@@ -13,8 +13,8 @@ import baby_sglang_amd as pkg  # noqa: E402
 dev = torch.device("cuda:0")
 hq, hkv, dim, dtype = 12, 2, 128, torch.bfloat16
 gen = torch.Generator(device=dev).manual_seed(0)
-for batch in (1, 2, 4, 8):
-    for seq in (1, 128, 2048, 4095):
+for batch in [int(b) for b in os.getenv("BATCHES", "1,2,4,8").split(",")]:
+    for seq in [int(x) for x in os.getenv("SEQS", "1,128,2048,4095").split(",")]:
         size = batch * 4096
         kv = pkg.MHATokenToKVPool(size, dtype, hkv, dim, 1, "cuda:0")
         kv.arena.normal_(generator=gen)
