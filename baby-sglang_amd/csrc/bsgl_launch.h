@@ -33,6 +33,7 @@ enum Knob : int {
   kKnobPrefill16,       // BSGL_PREFILL_16: keep the 16x16x32 extend kernel where the 32x32x16 form applies
   kKnobPrefillLdsPad,   // BSGL_PREFILL_LDS_PAD: extra LDS bytes per extend workgroup (lowers occupancy)
   kKnobP2PWaitMs,       // BSGL_P2P_WAIT_MS: how long a one-shot all-reduce waits for a peer (default 10000)
+  kKnobDecodeWhole,     // BSGL_DECODE_WHOLE: requests up to this many tokens stay in one piece where several waves share a piece (default 256)
   kKnobCount
 };
 int knob(Knob k);
@@ -80,6 +81,8 @@ struct DecodeArgs {
   // > balance_target: small batches whose requests turn out long may be cut finer, into up to this
   // many pieces per request, as long as a piece keeps at least 256 tokens (0: no such allowance)
   int32_t balance_target_hi;
+  // requests of up to this many tokens are not cut at all (0: every request is cut like the others)
+  int32_t whole_len;
   // matrix-core kernel, set by the host layer together with n_kv_heads = 1 and head_dim = 128 when
   // a model with two kv heads of 64 values is streamed as one 128-wide kv head: q heads per REAL kv
   // head (0 = not folded)

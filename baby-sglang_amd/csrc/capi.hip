@@ -47,6 +47,7 @@ constexpr KnobDef kKnobDefs[kKnobCount] = {
     {"BSGL_PREFILL_GROUP", 0},    {"BSGL_MFMA_NT", 1},             {"BSGL_MFMA_STAGES", 2},
     {"BSGL_MFMA_HPT", 1},         {"BSGL_MFMA_WAVES", 0},          {"BSGL_PREFILL_RT", 0},
     {"BSGL_PREFILL_16", 0},       {"BSGL_PREFILL_LDS_PAD", 0},     {"BSGL_P2P_WAIT_MS", 10000},
+    {"BSGL_DECODE_WHOLE", 256},
 };
 std::atomic<int> g_knobs[kKnobCount];
 std::once_flag g_knobs_once;
@@ -173,6 +174,7 @@ int run_decode(bsgl::DecodeArgs& a, int32_t variant, uint32_t* counters, hipStre
   // batch small enough for every workgroup to scan its seq_lens
   a.balance_target = 0;
   a.balance_target_hi = 0;
+  a.whole_len = 0;
   if (a.counters != nullptr && a.n_splits > 1 && a.rows <= 1024 && a.kv.table_cols <= (1 << 20) && !uniform_splits && bsgl::knob(bsgl::kKnobDecodeBalance) != 0)
     a.balance_target = (a.n_splits + 1) / 2;
   if (a.balance_target > 0) {
@@ -194,6 +196,16 @@ int run_decode(bsgl::DecodeArgs& a, int32_t variant, uint32_t* counters, hipStre
       const int64_t fine = a.kv.table_cols / 256;
       const int64_t hi = fine < (a.n_splits + 1) / 2 ? fine : (a.n_splits + 1) / 2;
       if (hi > a.balance_target) a.balance_target_hi = (int32_t)hi;
+    }
+    // (where a piece is shared by four waves: 256 pieces or fewer, as launch_decode_mfma decides)
+    {
+      // Short requests are not cut at all: one piece has no merge to wait for.  Measured (µs per
+      // layer call, 8 pieces against 1): 64 tokens 8.1 - 8.9 against 5.7 - 6.0 at any batch up to 32
+      // (64 requests: 8.8 against 7.1); 128 tokens 8.1 - 10.3 against 6.5 - 7.5 (64 requests: 11.5 against
+      // 10.1); 256 tokens 9.2 - 9.6 against 8.0 - 8.2 where four waves share a piece (256 pieces or
+      // fewer, as launch_decode_mfma decides), but 9.7 - 11.9 against 10.7 - 16.1 beyond.
+      const int whole = bsgl::knob(bsgl::kKnobDecodeWhole);
+      a.whole_len = (int64_t)a.rows * a.n_kv_heads * a.balance_target <= 256 ? whole : whole / 2;
     }
     const int t = bsgl::knob(bsgl::kKnobDecodeTarget);  // tuning override: pieces wanted per request
     if (t > 0 && t <= a.n_splits) {

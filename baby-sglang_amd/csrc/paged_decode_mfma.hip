@@ -189,6 +189,7 @@ void decode_mfma_kernel(DecodeArgs a) {
       int piece_len = small_div(len_first + a.balance_target - 1, a.balance_target);
       if (a.balance_target_hi > a.balance_target)
         piece_len = max(small_div(len_first + a.balance_target_hi - 1, a.balance_target_hi), min(kFinePiece, piece_len));
+      if (len_first <= a.whole_len) piece_len = len_first;
       piece_len = max(kTile, (piece_len + kTile - 1) / kTile * kTile);
       const int parts = __builtin_amdgcn_readfirstlane(min(a.n_splits, max(1, small_div(len_first + piece_len - 1, piece_len))));
       row = __builtin_amdgcn_readfirstlane(small_div(piece, parts));
@@ -220,7 +221,7 @@ void decode_mfma_kernel(DecodeArgs a) {
       row = -1;
       for (int r0 = 0; r0 < a.rows; r0 += 64) {
         const int s = r0 == 0 ? len0 : len_of(r0 + lane);
-        const int parts = r0 + lane < a.rows ? min(a.n_splits, max(1, small_div(s + piece_len - 1, piece_len))) : 0;
+        const int parts = r0 + lane >= a.rows ? 0 : s <= a.whole_len ? 1 : min(a.n_splits, max(1, small_div(s + piece_len - 1, piece_len)));
         const int incl = wave_inclusive_scan<ScanAdd>(parts);
         const int blk_total = __builtin_amdgcn_readlane(incl, 63);
         if (row < 0 && piece < base + blk_total) {
