@@ -226,7 +226,7 @@ def test_pieces_shared_by_the_waves_of_a_workgroup(gpu, dtype, hq, hkv, dim, wav
 @pytest.mark.parametrize("hq", [14, 4, 16])
 def test_two_kv_heads_of_64_on_the_matrix_core_kernel(gpu, dtype, hq):
     """Two kv heads of 64 values (Qwen2.5-0.5B: 14 q heads) streamed as one 128-wide kv head:
-    forced matrix-core variant (the automatic choice only folds from 32 requests on) against the
+    forced matrix-core variant (and the automatic choice, which folds too) against the
     float64 oracle, with the new token's rows written by the kernel, f32 output + lse, every
     split count incl. the unsplit direct path, and a batch large enough for the automatic choice."""
     from baby_sglang_amd import _hip

@@ -11,7 +11,8 @@ sys.path.insert(0, ROOT)
 import baby_sglang_amd as pkg  # noqa: E402
 
 dev = torch.device("cuda:0")
-hq, hkv, dim, dtype = 12, 2, 128, torch.bfloat16
+hq, hkv, dim = (int(x) for x in os.getenv("SHAPE", "12,2,128").split(","))  # q heads, kv heads, head dim
+dtype = torch.bfloat16
 gen = torch.Generator(device=dev).manual_seed(0)
 for batch in [int(b) for b in os.getenv("BATCHES", "1,2,4,8").split(",")]:
     for seq in [int(x) for x in os.getenv("SEQS", "1,128,2048,4095").split(",")]:
@@ -30,7 +31,7 @@ for batch in [int(b) for b in os.getenv("BATCHES", "1,2,4,8").split(",")]:
         out = torch.empty((batch, hq * dim), dtype=dtype, device=dev)
 
         def call():
-            pkg._hip.paged_decode(q, k_slab, v_slab, table, rows, sl, n_splits=n_splits, out=out, workspace=ws,
+            pkg._hip.paged_decode(q, k_slab, v_slab, table, rows, sl, n_splits=n_splits, out=out, workspace=ws, variant=int(os.getenv("VARIANT", "0")),
                                   k_new=k_new, v_new=k_new, out_cache_loc=loc, fuse_kv_write=True)
 
         for _ in range(3):
