@@ -16,6 +16,8 @@ sys.path.insert(0, ROOT)
 import baby_sglang_amd as pkg  # noqa: E402
 
 SHAPES = {
+    "0.5b": dict(hidden_size=896, intermediate_size=4864, num_hidden_layers=24, num_attention_heads=14,
+                 num_key_value_heads=2, vocab_size=151936),
     "1.5b": dict(hidden_size=1536, intermediate_size=8960, num_hidden_layers=28, num_attention_heads=12,
                  num_key_value_heads=2, vocab_size=151936),
     "7b": dict(hidden_size=3584, intermediate_size=18944, num_hidden_layers=28, num_attention_heads=28,
@@ -33,7 +35,7 @@ def main():
     dev = torch.device("cuda:0")
     dtype = torch.bfloat16
     cfg = types.SimpleNamespace(**SHAPES[args.model], rms_norm_eps=1e-6, rope_theta=1000000.0, rope_scaling=None,
-                                max_position_embeddings=32768, tie_word_embeddings=args.model == "1.5b", hidden_act="silu")
+                                max_position_embeddings=32768, tie_word_embeddings=args.model in ("0.5b", "1.5b"), hidden_act="silu")
     torch.manual_seed(0)
     with torch.device(dev):
         model = pkg.BabyQwen2ForCausalLM(cfg).to(dtype).eval()
