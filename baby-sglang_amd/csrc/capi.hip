@@ -202,11 +202,11 @@ int run_decode(bsgl::DecodeArgs& a, int32_t variant, uint32_t* counters, hipStre
     {
       // Short requests are not cut at all: one piece has no merge to wait for.  Measured (µs per
       // layer call, 8 pieces against 1): 64 tokens 8.1 - 8.9 against 5.7 - 6.0 at any batch up to 32
-      // (64 requests: 8.8 against 7.1); 128 tokens 8.1 - 10.3 against 6.5 - 7.5 (64 requests: 11.5 against
-      // 10.1); 256 tokens 9.2 - 9.6 against 8.0 - 8.2 where four waves share a piece (256 pieces or
-      // fewer, as launch_decode_mfma decides), but 9.7 - 11.9 against 10.7 - 16.1 beyond.
+      // (64 requests: 8.8 against 7.1); 128 tokens 8.1 - 10.3 against 6.5 - 6.7 (64 requests: 11.5 against
+      // 10.1); 256 tokens 9.2 - 11.0 against 8.0 - 8.3 where four waves share a piece (512 pieces or
+      // fewer, as launch_decode_mfma decides), but 11.9 against 16.1 beyond.
       const int whole = bsgl::knob(bsgl::kKnobDecodeWhole);
-      a.whole_len = (int64_t)a.rows * a.n_kv_heads * a.balance_target <= 256 ? whole : whole / 2;
+      a.whole_len = (int64_t)a.rows * a.n_kv_heads * a.balance_target <= 512 ? whole : whole / 2;
     }
     const int t = bsgl::knob(bsgl::kKnobDecodeTarget);  // tuning override: pieces wanted per request
     if (t > 0 && t <= a.n_splits) {
