@@ -36,7 +36,6 @@
 
 #include <cstdio>
 #include <cstring>
-#include <mutex>
 
 namespace bsgl {
 int set_error(int code, const char* msg);
