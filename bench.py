@@ -675,6 +675,19 @@ def main():
             }
         except Exception as exc:
             extras["larger_decode_launches_error"] = repr(exc)
+        try:
+            # BASELINE configs[0] and [1] as single layer calls: one request (and eight) on the 1.5B and the
+            # 0.5B shapes, microseconds per KV write + decode launch incl. the launch boundary, graph replay
+            from tools import bench_latency as latency
+
+            torch.cuda.empty_cache()
+            extras["small_batch_decode_us_per_layer"] = {
+                f"{name} shapes, batch {b} x {s_} tokens": round(latency.measure(hq, hkv, d, b, s_, 0, dev)[0], 2)
+                for name, (hq, hkv, d) in (("1.5b", (12, 2, 128)), ("0.5b", (14, 2, 64)))
+                for b in (1, 8) for s_ in (128, 2048, 4095)
+            }
+        except Exception as exc:
+            extras["small_batch_decode_error"] = repr(exc)
         result["extras"] = extras
 
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
