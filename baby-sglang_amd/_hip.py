@@ -60,7 +60,7 @@ class DecodeCall(ctypes.Structure):
         ("req_to_token", _vp), ("table_row_stride", _i64), ("table_rows", _i64), ("table_cols", _i64),
         ("req_pool_indices", _vp), ("seq_lens", _vp),
         ("batch", _i32), ("n_q_heads", _i32), ("n_kv_heads", _i32), ("head_dim", _i32),
-        ("scale", _f32), ("dtype", _i32), ("out_dtype", _i32), ("n_splits", _i32), ("variant", _i32), ("reserved", _i32),
+        ("scale", _f32), ("dtype", _i32), ("out_dtype", _i32), ("n_splits", _i32), ("variant", _i32), ("max_seq_len", _i32),
         ("workspace", _vp), ("workspace_bytes", _sz), ("stream", _vp),
     ]  # fmt: skip
 
@@ -286,6 +286,7 @@ def paged_decode(
     fuse_kv_write: bool = False,
     uniform_splits: bool = False,
     static_scratch: bool = False,
+    max_seq_len: int = 0,
     _plan: Optional[tuple] = None,
 ) -> torch.Tensor:
     """softmax(q K^T * scale) V over page-table rows; returns [B, Hq * D].
@@ -306,6 +307,8 @@ def paged_decode(
     equal pieces per request.  ``static_scratch`` takes the entry point that allocates
     nothing (``bsgl_paged_decode_static``: the split merge's workspace is an array inside the
     library, 16 MiB per GPU, shared by all such calls on that GPU); ``out`` must then be given.
+    ``max_seq_len`` (0 = unknown) tells the library that no request is longer: a hint for the
+    shape of the launch only, results never depend on it.
     """
     # (this wrapper runs once per layer and decode step beside a ~30 us kernel: every tensor's
     # shape and strides are asked for once)
@@ -378,6 +381,21 @@ def paged_decode(
             _plan[1] if _plan is not None else _stream_ptr(q.device),
         )  # fmt: skip
         _check(rc, "bsgl_paged_decode_static")
+        return out
+    if max_seq_len > 0:
+        # (the hint travels in the call descriptor only)
+        c = DecodeCall()
+        c.out, c.out_row_stride, c.lse = out.data_ptr(), out.stride(0), lse.data_ptr() if lse is not None else None
+        c.q, c.q_row_stride = q.data_ptr(), q_stride[0]
+        c.k_new, c.v_new, c.k_new_row_stride, c.v_new_row_stride, c.out_cache_loc = new
+        c.k_slab, c.v_slab, c.slab_row_stride, c.n_slots = k_slab.data_ptr(), v_slab.data_ptr(), k_stride0, k_shape[0]
+        c.req_to_token, c.table_row_stride, c.table_rows, c.table_cols = req_to_token.data_ptr(), t_stride[0], t_shape[0], t_shape[1]
+        c.req_pool_indices, c.seq_lens = req_pool_indices.data_ptr(), seq_lens.data_ptr()
+        c.batch, c.n_q_heads, c.n_kv_heads, c.head_dim, c.scale = batch, hq, hkv, dim, scale
+        c.dtype, c.out_dtype, c.n_splits, c.variant, c.max_seq_len = q_code, _DTYPE_CODE[out_dtype], n_splits, variant, int(max_seq_len)
+        c.workspace, c.workspace_bytes = workspace.data_ptr() if need else None, ws_bytes
+        c.stream = _plan[1] if _plan is not None else _stream_ptr(q.device)
+        _check(lib.bsgl_paged_decode_call(ctypes.byref(c)), "bsgl_paged_decode_call")
         return out
     rc = lib.bsgl_paged_decode(
         out.data_ptr(), out.stride(0), lse.data_ptr() if lse is not None else None,

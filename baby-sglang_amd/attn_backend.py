@@ -222,6 +222,8 @@ class SimpleAttentionBackend:
             c.req_pool_indices, c.seq_lens = step[1], step[2]
             c.workspace = step[4] if c.workspace_bytes else None
             c.stream = stream
+            # (a scheduler that knows its longest request says so on the batch; the reference's does not)
+            c.max_seq_len = getattr(forward_batch, "max_seq_len", 0) or 0
             rec[4] = step
         c.variant = variant
         rc = _hip.lib.bsgl_paged_decode_call(rec[3])

@@ -83,6 +83,10 @@ struct DecodeArgs {
   int32_t balance_target_hi;
   // requests of up to this many tokens are not cut at all (0: every request is cut like the others)
   int32_t whole_len;
+  // the caller's word that no request is longer than this (0: unknown); shapes the launch only
+  int32_t len_hint;
+  // waves that share a piece, chosen by the host layer from len_hint (0: by the piece count)
+  int32_t hint_waves;
   // matrix-core kernel, set by the host layer together with n_kv_heads = 1 and head_dim = 128 when
   // a model with two kv heads of 64 values is streamed as one 128-wide kv head: q heads per REAL kv
   // head (0 = not folded)

@@ -208,6 +208,20 @@ int run_decode(bsgl::DecodeArgs& a, int32_t variant, uint32_t* counters, hipStre
       const int whole = bsgl::knob(bsgl::kKnobDecodeWhole);
       a.whole_len = (int64_t)a.rows * a.n_kv_heads * a.balance_target <= 512 ? whole : whole / 2;
     }
+    // A caller that knows its longest request (bsgl_decode_call::max_seq_len) and has only short ones:
+    // the rules above are made for requests as long as the page table is wide.  Up to 256 tokens every
+    // request is one piece, so the launch has rows x kv heads pieces, shared by four waves each up to 256
+    // of them and by two up to 1024 (64 requests of 128 tokens: 10.1 -> 6.9 us per layer call, 64 x 256:
+    // 11.8 -> 8.8, 128 x 256: 13.4 -> 10.8, 256 x 256: 19.3 -> 16.6; at 512 tokens little is left to gain).
+    a.hint_waves = 0;
+    if (a.len_hint > 0 && a.len_hint <= 256 && a.fold_group == 0) {
+      const int64_t units = (int64_t)a.rows * a.n_kv_heads;
+      a.whole_len = 256;
+      a.hint_waves = units <= 256 ? 4 : units <= 1024 ? 2 : 1;
+      // (one piece per request: the flat grid need not hold room for more)
+      a.balance_target = 1;
+      a.balance_target_hi = 0;
+    }
     const int t = bsgl::knob(bsgl::kKnobDecodeTarget);  // tuning override: pieces wanted per request
     if (t > 0 && t <= a.n_splits) {
       a.balance_target = t;
@@ -370,7 +384,7 @@ int decode_entry(void* out, int64_t out_row_stride, float* lse, const void* q, i
                  int64_t table_cols, const int64_t* req_pool_indices, const int64_t* seq_lens,
                  int32_t batch, int32_t n_q_heads, int32_t n_kv_heads, int32_t head_dim, float scale,
                  int32_t dtype, int32_t out_dtype, int32_t n_splits, int32_t variant,
-                 void* workspace, size_t workspace_bytes, bool static_scratch, void* stream) {
+                 void* workspace, size_t workspace_bytes, bool static_scratch, int32_t max_seq_len, void* stream) {
   if (batch < 0) return fail(BSGL_ERR_BAD_ARG, "batch < 0");
   if (out_dtype != dtype && out_dtype != BSGL_DTYPE_F32)
     return fail(BSGL_ERR_BAD_ARG, "out_dtype must equal dtype or be f32");
@@ -439,6 +453,7 @@ int decode_entry(void* out, int64_t out_row_stride, float* lse, const void* q, i
   a.dtype = dtype;
   a.out_dtype = out_dtype;
   a.n_splits = n_splits;
+  a.len_hint = max_seq_len > 0 ? max_seq_len : 0;
   const size_t rh = (size_t)batch * (size_t)n_q_heads;
   const size_t cb = kCounterBytes;
   a.ws_o = need ? (float*)((char*)workspace + cb) : nullptr;
@@ -460,7 +475,7 @@ int bsgl_paged_decode(void* out, int64_t out_row_stride, float* lse, const void*
   return decode_entry(out, out_row_stride, lse, q, q_row_stride, k_new, v_new, k_new_row_stride, v_new_row_stride,
                       out_cache_loc, k_slab, v_slab, slab_row_stride, n_slots, req_to_token, table_row_stride,
                       table_rows, table_cols, req_pool_indices, seq_lens, batch, n_q_heads, n_kv_heads, head_dim,
-                      scale, dtype, out_dtype, n_splits, variant, workspace, workspace_bytes, false, stream);
+                      scale, dtype, out_dtype, n_splits, variant, workspace, workspace_bytes, false, 0, stream);
 }
 
 int bsgl_paged_decode_call(const bsgl_decode_call* c) {
@@ -469,7 +484,7 @@ int bsgl_paged_decode_call(const bsgl_decode_call* c) {
                       c->v_new_row_stride, c->out_cache_loc, c->k_slab, c->v_slab, c->slab_row_stride, c->n_slots,
                       c->req_to_token, c->table_row_stride, c->table_rows, c->table_cols, c->req_pool_indices, c->seq_lens,
                       c->batch, c->n_q_heads, c->n_kv_heads, c->head_dim, c->scale, c->dtype, c->out_dtype, c->n_splits,
-                      c->variant, c->workspace, c->workspace_bytes, false, c->stream);
+                      c->variant, c->workspace, c->workspace_bytes, false, c->max_seq_len, c->stream);
 }
 
 int bsgl_paged_decode_static(void* out, int64_t out_row_stride, float* lse, const void* q, int64_t q_row_stride,
@@ -483,7 +498,7 @@ int bsgl_paged_decode_static(void* out, int64_t out_row_stride, float* lse, cons
   return decode_entry(out, out_row_stride, lse, q, q_row_stride, k_new, v_new, k_new_row_stride, v_new_row_stride,
                       out_cache_loc, k_slab, v_slab, slab_row_stride, n_slots, req_to_token, table_row_stride,
                       table_rows, table_cols, req_pool_indices, seq_lens, batch, n_q_heads, n_kv_heads, head_dim,
-                      scale, dtype, out_dtype, n_splits, variant, nullptr, 0, true, stream);
+                      scale, dtype, out_dtype, n_splits, variant, nullptr, 0, true, 0, stream);
 }
 
 static int32_t prefill_row_splits(int32_t total_q_tokens, int32_t max_context_len) {

@@ -775,6 +775,7 @@ hipError_t launch_tag(const DecodeArgs& a, hipStream_t stream) {
   // 512 and 1024 pieces two waves win at 1024 tokens and lose at 2048 and beyond.)
   const int64_t n_pieces = (int64_t)a.rows * a.n_kv_heads * (a.balance_target > 0 ? a.balance_target : a.n_splits);
   int waves = n_pieces > 512 ? 1 : 4;
+  if (a.balance_target > 0 && (a.hint_waves == 1 || a.hint_waves == 2 || a.hint_waves == 4)) waves = a.hint_waves;
   {
     const int forced = knob(kKnobMfmaWaves);  // tuning override
     if (forced == 1 || forced == 2 || forced == 4) waves = forced;

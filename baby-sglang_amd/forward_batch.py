@@ -36,6 +36,11 @@ class SimplifiedForwardBatch:
     prefix_lens: Optional[torch.Tensor] = None
     extended_lens: Optional[torch.Tensor] = None
 
+    # Not in the reference: the longest request of a decode batch, when the scheduler knows it on
+    # the host (0 = unknown).  The backend hands it to the library as a hint for the shape of the
+    # launch; results never depend on it.
+    max_seq_len: int = 0
+
     @classmethod
     def create_prefill_batch(
         cls,

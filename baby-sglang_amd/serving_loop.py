@@ -492,7 +492,7 @@ class ServingLoop:
             input_ids = self._last_ids[rows_t]
         else:
             input_ids = self._h2d([s.output_ids[-1] for s in batch], torch.long)
-        return SimplifiedForwardBatch.create_decode_batch(
+        fb = SimplifiedForwardBatch.create_decode_batch(
             input_ids=input_ids,
             req_pool_indices=rows_t,
             seq_lens=seq_t,
@@ -500,6 +500,8 @@ class ServingLoop:
             req_to_token_pool=self.req_to_token_pool,
             token_to_kv_pool=self.token_to_kv_pool,
         )
+        fb.max_seq_len = max(s.seq_len for s in batch)  # (known here without asking the device)
+        return fb
 
     # ---------------------------------------------------------------------------- results
     def _finish_step(self, next_ids: List[int], batch: List[Sequence_], mode: str) -> None:

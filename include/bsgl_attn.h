@@ -195,7 +195,9 @@ typedef struct bsgl_decode_call {
   int32_t out_dtype;
   int32_t n_splits;
   int32_t variant;
-  int32_t reserved; /* 0 */
+  int32_t max_seq_len; /* 0 = unknown; else no request of this call is longer.  A HINT for the shape of
+                          the launch only (a host sees the page table's width, not the lengths): results
+                          never depend on it, a wrong value costs time */
   void* workspace;
   size_t workspace_bytes;
   void* stream;

@@ -98,3 +98,32 @@ def test_two_threads_on_two_streams(gpu):
         t.join()
     if errors:
         raise errors[0]
+
+
+def test_a_batch_that_names_its_longest_request(gpu):
+    """A scheduler that knows its longest request on the host says so on the batch
+    (``SimplifiedForwardBatch.max_seq_len``, not a field of the reference's descriptor); the backend
+    hands it to the library as a hint.  Same batch object, with the hint, without it, and with one
+    that is wrong: all three against the oracle, the new rows written by the kernel each time."""
+    import baby_sglang_amd as pkg
+
+    dtype, hq, hkv, dim = torch.bfloat16, 12, 2, 128
+    layer = types.SimpleNamespace(layer_id=0, scaling=dim**-0.5)
+    gen = torch.Generator().manual_seed(3)
+    seq_lens = torch.randint(1, 201, (64,), generator=gen).tolist()
+    cpu, r2t, kv = random_decode_problem(gpu, dtype, hq, hkv, dim, seq_lens, seed=91)
+    k_new = torch.randn((64, hkv, dim), generator=gen).to(dtype)
+    v_new = torch.randn((64, hkv, dim), generator=gen).to(dtype)
+    loc = cpu["req_to_token"][cpu["req_pool_indices"], cpu["seq_lens"] - 1].to(torch.int32)
+    orc.kv_scatter_ref(cpu["k_slab"], cpu["v_slab"], loc, k_new, v_new)
+    want = orc.decode_exact(cpu["q"], cpu["k_slab"], cpu["v_slab"], cpu["req_to_token"], cpu["req_pool_indices"], cpu["seq_lens"])
+    q, kn, vn = cpu["q"].to(gpu), k_new.to(gpu), v_new.to(gpu)
+    for hint in (max(seq_lens), 0, 5):
+        fb = pkg.SimplifiedForwardBatch.create_decode_batch(torch.zeros(64, dtype=torch.int64, device=gpu), cpu["req_pool_indices"].to(gpu),
+                                                            cpu["seq_lens"].to(gpu), loc.to(gpu), r2t, kv)
+        assert fb.max_seq_len == 0
+        fb.max_seq_len = hint
+        out = pkg.SimpleAttentionBackend.forward(q, kn, vn, layer, fb)
+        assert_close(out, want, dtype, f"hint {hint}")
+        k_slab, v_slab = kv.get_kv_buffer(0)
+        assert torch.equal(k_slab.cpu(), cpu["k_slab"]) and torch.equal(v_slab.cpu(), cpu["v_slab"])

@@ -404,6 +404,46 @@ def test_small_batches_of_long_requests(gpu, seq_lens, hq, hkv):
     assert torch.equal(k_slab.cpu(), cpu["k_slab"]) and torch.equal(v_slab.cpu(), cpu["v_slab"])
 
 
+@pytest.mark.parametrize("case", [
+    ("64 short, exact hint", 64, 256, 256, 12, 2, 128),
+    ("128 short, exact hint", 128, 200, 200, 12, 2, 128),
+    ("300 short: two waves per piece", 300, 100, 100, 12, 2, 128),
+    ("700 short: one wave per piece", 700, 60, 60, 12, 2, 128),
+    ("7B shapes", 40, 256, 256, 28, 4, 128),
+    ("folded heads take no hint", 64, 256, 256, 14, 2, 64),
+    ("hint larger than 256: no effect", 64, 700, 700, 12, 2, 128),
+    ("a hint that is too small", 48, 2000, 64, 12, 2, 128),
+    ("a hint that is far too small", 3, 4000, 1, 12, 2, 128),
+])
+def test_length_hint_shapes_the_launch_only(gpu, case):
+    """``max_seq_len`` (bsgl_decode_call) is a caller's word that no request is longer; batches of
+    short requests are then launched as what they are (every request one piece, four or two waves
+    per piece).  Results must not depend on it: ragged batches against the oracle with a true hint,
+    and with hints that are wrong."""
+    from baby_sglang_amd import _hip
+
+    name, batch, longest, hint, hq, hkv, dim = case
+    dtype = torch.bfloat16
+    gen = torch.Generator().manual_seed(batch + longest)
+    seq_lens = torch.randint(1, longest + 1, (batch,), generator=gen).tolist()
+    seq_lens[0] = longest
+    cpu, r2t, kv = random_decode_problem(gpu, dtype, hq, hkv, dim, seq_lens, seed=batch * 7 + hint)
+    k_new = torch.randn((batch, hkv, dim), generator=gen).to(dtype)
+    v_new = torch.randn((batch, hkv, dim), generator=gen).to(dtype)
+    loc = cpu["req_to_token"][cpu["req_pool_indices"], cpu["seq_lens"] - 1].to(torch.int32)
+    orc.kv_scatter_ref(cpu["k_slab"], cpu["v_slab"], loc, k_new, v_new)
+    want, want_lse = orc.decode_exact(cpu["q"], cpu["k_slab"], cpu["v_slab"], cpu["req_to_token"],
+                                      cpu["req_pool_indices"], cpu["seq_lens"], return_lse=True)
+    k_slab, v_slab = kv.get_kv_buffer(0)
+    lse = torch.empty((batch, hq), dtype=torch.float32, device=gpu)
+    out = _hip.paged_decode(cpu["q"].to(gpu), k_slab, v_slab, r2t.req_to_token, cpu["req_pool_indices"].to(gpu),
+                            cpu["seq_lens"].to(gpu), lse=lse, k_new=k_new.to(gpu), v_new=v_new.to(gpu),
+                            out_cache_loc=loc.to(gpu), fuse_kv_write=True, max_seq_len=hint)
+    assert_close(out, want, dtype, name)
+    assert (lse.cpu().double() - want_lse).abs().max().item() < 2e-3, name
+    assert torch.equal(k_slab.cpu(), cpu["k_slab"]) and torch.equal(v_slab.cpu(), cpu["v_slab"]), name
+
+
 def test_decode_empty_and_zero_length(gpu):
     from baby_sglang_amd import _hip
 

@@ -2,7 +2,8 @@
 """Decode latency of one layer call at small and medium batch (BASELINE configs[1]: Qwen2.5-1.5B
 bf16, batch 1): microseconds per paged_decode launch, replayed from a HIP graph, for several
 context lengths.  Environment: SHAPE="q heads,kv heads,head dim" (default 12,2,128), BATCHES and
-SEQS (comma lists), VARIANT (0 automatic, 1 generic kernel, 2 matrix-core kernel); the library's
+SEQS (comma lists), VARIANT (0 automatic, 1 generic kernel, 2 matrix-core kernel), HINT=1 (the calls say how
+long their longest request is); the library's
 own knobs (BSGL_*) apply as always."""
 import os
 import sys
@@ -14,7 +15,7 @@ sys.path.insert(0, ROOT)
 import baby_sglang_amd as pkg  # noqa: E402
 
 
-def measure(hq, hkv, dim, batch, seq, variant=0, dev=None, max_ctx=4096, dtype=torch.bfloat16):
+def measure(hq, hkv, dim, batch, seq, variant=0, dev=None, max_ctx=4096, dtype=torch.bfloat16, hint=0):
     """(microseconds per layer call incl. the launch boundary, n_splits): KV write + paged decode of
     `batch` requests of `seq` tokens on a random-permutation page table of `max_ctx` columns."""
     dev = dev or torch.device("cuda:0")
@@ -34,7 +35,7 @@ def measure(hq, hkv, dim, batch, seq, variant=0, dev=None, max_ctx=4096, dtype=t
     out = torch.empty((batch, hq * dim), dtype=dtype, device=dev)
 
     def call():
-        pkg._hip.paged_decode(q, k_slab, v_slab, table, rows, sl, n_splits=n_splits, out=out, workspace=ws, variant=variant,
+        pkg._hip.paged_decode(q, k_slab, v_slab, table, rows, sl, n_splits=n_splits, out=out, workspace=ws, variant=variant, max_seq_len=hint,
                               k_new=k_new, v_new=k_new, out_cache_loc=loc, fuse_kv_write=True)
 
     for _ in range(3):
@@ -60,7 +61,7 @@ def main():
     variant = int(os.getenv("VARIANT", "0"))
     for batch in [int(b) for b in os.getenv("BATCHES", "1,2,4,8").split(",")]:
         for seq in [int(x) for x in os.getenv("SEQS", "1,128,2048,4095").split(",")]:
-            us, n_splits = measure(hq, hkv, dim, batch, seq, variant)
+            us, n_splits = measure(hq, hkv, dim, batch, seq, variant, hint=seq if os.getenv("HINT", "0") != "0" else 0)
             print(f"batch={batch} seq={seq:5d} splits={n_splits:2d}: {us:7.2f} us per layer call (incl. launch boundary)", flush=True)
 
 
