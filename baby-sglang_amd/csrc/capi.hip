@@ -212,9 +212,10 @@ int run_decode(bsgl::DecodeArgs& a, int32_t variant, uint32_t* counters, hipStre
     // the rules above are made for requests as long as the page table is wide.  Up to 256 tokens every
     // request is one piece, so the launch has rows x kv heads pieces, shared by four waves each up to 256
     // of them and by two up to 1024 (64 requests of 128 tokens: 10.1 -> 6.9 us per layer call, 64 x 256:
-    // 11.8 -> 8.8, 128 x 256: 13.4 -> 10.8, 256 x 256: 19.3 -> 16.6; at 512 tokens little is left to gain).
+    // 11.8 -> 8.8, 128 x 256: 13.4 -> 10.8, 256 x 256: 19.3 -> 16.6; two kv heads of 64 values folded into one:
+    // 128 x 256: 17.8 -> 10.4; at 512 tokens little is left to gain).
     a.hint_waves = 0;
-    if (a.len_hint > 0 && a.len_hint <= 256 && a.fold_group == 0) {
+    if (a.len_hint > 0 && a.len_hint <= 256) {
       const int64_t units = (int64_t)a.rows * a.n_kv_heads;
       a.whole_len = 256;
       a.hint_waves = units <= 256 ? 4 : units <= 1024 ? 2 : 1;
@@ -231,7 +232,7 @@ int run_decode(bsgl::DecodeArgs& a, int32_t variant, uint32_t* counters, hipStre
   // (folded heads: the workgroup that merges a request reads the partial rows of ALL its q heads,
   // 14 for Qwen2.5-0.5B: more than 8 pieces per request cost more in that merge than they gain)
   // -- and with half as many kv heads to cut, up to n_splits pieces are wanted below that
-  if (a.fold_group > 0 && a.balance_target > 0) {
+  if (a.fold_group > 0 && a.balance_target > 0 && a.hint_waves == 0) {
     const int cap = bsgl::knob(bsgl::kKnobFoldPieces);
     a.balance_target = a.n_splits < cap ? a.n_splits : cap;
     a.balance_target_hi = 0;

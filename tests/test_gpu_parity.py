@@ -410,7 +410,9 @@ def test_small_batches_of_long_requests(gpu, seq_lens, hq, hkv):
     ("300 short: two waves per piece", 300, 100, 100, 12, 2, 128),
     ("700 short: one wave per piece", 700, 60, 60, 12, 2, 128),
     ("7B shapes", 40, 256, 256, 28, 4, 128),
-    ("folded heads take no hint", 64, 256, 256, 14, 2, 64),
+    ("two kv heads of 64 values, folded", 64, 256, 256, 14, 2, 64),
+    ("folded, more requests", 200, 180, 180, 14, 2, 64),
+    ("folded, a hint that is too small", 130, 1500, 100, 14, 2, 64),
     ("hint larger than 256: no effect", 64, 700, 700, 12, 2, 128),
     ("a hint that is too small", 48, 2000, 64, 12, 2, 128),
     ("a hint that is far too small", 3, 4000, 1, 12, 2, 128),
