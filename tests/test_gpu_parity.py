@@ -795,6 +795,12 @@ def test_random_shapes_against_the_oracle(gpu, seed):
                             k_new=k_new.to(gpu), v_new=v_new.to(gpu), out_cache_loc=loc, fuse_kv_write=pick([True, False]))
     assert_close(out, want, dtype, f"decode {hq}/{hkv}/{dim} {dtype} batch {batch} splits {n_splits} {layout}")
     assert torch.equal(k_slab.cpu(), k_ref) and torch.equal(v_slab.cpu(), v_ref)
+    # the same call from a caller that names its longest request -- truthfully or not
+    hint = [max(seq_lens), 1, 64, 256, 5000][seed % 5]
+    out = _hip.paged_decode(cpu["q"].to(gpu), k_slab, v_slab, r2t.req_to_token, rows, seq, n_splits=n_splits, max_seq_len=hint,
+                            k_new=k_new.to(gpu), v_new=v_new.to(gpu), out_cache_loc=loc, fuse_kv_write=True)
+    assert_close(out, want, dtype, f"decode {hq}/{hkv}/{dim} {dtype} batch {batch} splits {n_splits} {layout} hint {hint}")
+    assert torch.equal(k_slab.cpu(), k_ref) and torch.equal(v_slab.cpu(), v_ref)
     # extend of the same requests over random prefixes
     prefix = [int(torch.randint(0, n, (1,), generator=gen)) if n > 1 and pick([True, False]) else 0 for n in seq_lens]
     ext = [n - p for n, p in zip(seq_lens, prefix)]
