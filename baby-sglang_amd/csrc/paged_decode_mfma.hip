@@ -187,8 +187,13 @@ void decode_mfma_kernel(DecodeArgs a) {
                             __all(lane >= a.rows || len0 == len_first);
     if (equal_lens) {
       int piece_len = small_div(len_first + a.balance_target - 1, a.balance_target);
-      if (a.balance_target_hi > a.balance_target)
-        piece_len = max(small_div(len_first + a.balance_target_hi - 1, a.balance_target_hi), min(kFinePiece, piece_len));
+      // (the finer cut is for launches of few pieces, which share a piece among several waves: the
+      // one-wave form does not carry its code -- the headline launch was 0.4 % slower with it, for
+      // no more than a handful of scalar instructions: this kernel sits at its scalar-register limit)
+      if constexpr (W > 1) {
+        if (a.balance_target_hi > a.balance_target)
+          piece_len = max(small_div(len_first + a.balance_target_hi - 1, a.balance_target_hi), min(kFinePiece, piece_len));
+      }
       if (len_first <= a.whole_len) piece_len = len_first;
       piece_len = max(kTile, (piece_len + kTile - 1) / kTile * kTile);
       const int parts = __builtin_amdgcn_readfirstlane(min(a.n_splits, max(1, small_div(len_first + piece_len - 1, piece_len))));
@@ -207,9 +212,11 @@ void decode_mfma_kernel(DecodeArgs a) {
     }
     int want = a.rows * a.balance_target;
     int piece_len = max((tot + want - 1) / want, small_div(longest + a.n_splits - 1, a.n_splits));  // (lengths are capped at 2^20)
-    if (a.balance_target_hi > a.balance_target) {
-      want = a.rows * a.balance_target_hi;
-      piece_len = max((tot + want - 1) / want, min(kFinePiece, piece_len));
+    if constexpr (W > 1) {
+      if (a.balance_target_hi > a.balance_target) {
+        want = a.rows * a.balance_target_hi;
+        piece_len = max((tot + want - 1) / want, min(kFinePiece, piece_len));
+      }
     }
     piece_len = max(kTile, (piece_len + kTile - 1) / kTile * kTile);
     // Rounding up per request can leave up to `rows` pieces more than wanted: a few CUs would
@@ -746,7 +753,7 @@ template <typename Tag, int HPT, int NSTAGE>
 hipError_t launch_inst(const DecodeArgs& a, hipStream_t stream) {
   dim3 grid(a.rows, a.n_kv_heads / HPT, a.n_splits);
   // flat list of length-balanced pieces: at most rows * target + rows of them
-  if (a.balance_target > 0) grid = dim3((unsigned)((int64_t)a.rows * (max(a.balance_target, a.balance_target_hi) + 1) * (a.n_kv_heads / HPT)), 1, 1);
+  if (a.balance_target > 0) grid = dim3((unsigned)((int64_t)a.rows * (a.balance_target + 1) * (a.n_kv_heads / HPT)), 1, 1);
   // (the per-workgroup timeline is a build of its own, kept for the default configuration only:
   // as a run-time flag its stamps cost the untraced launches 0.1 - 0.7 %)
   if (HPT == 1 && NSTAGE == 2 && a.trace != nullptr && knob(kKnobMfmaNT))
