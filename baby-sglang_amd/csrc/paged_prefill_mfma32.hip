@@ -27,6 +27,13 @@
 
 #include <type_traits>
 
+// Timing cuts of this translation unit (bit mask, tools/build_variant.sh sets it; RESULTS ARE WRONG
+// with any of them, they exist to price a phase): 4 = no K/V request inside the step loop, 8 = no
+// exponentials / multiply-adds / row sums / maxima, 64 = half of a step's K/V requests.
+#ifndef BSGL_CUT
+#define BSGL_CUT 0
+#endif
+
 namespace bsgl {
 
 namespace {
@@ -86,6 +93,7 @@ void prefill_mfma32_kernel(PrefillArgs a) {
 
   const int tid = threadIdx.x;
   const uint64_t t_entry = PROF ? __builtin_readcyclecounter() : 0;
+  const uint64_t rt_entry = PROF ? __builtin_amdgcn_s_memrealtime() : 0;  // 100 MHz ticks: the clock the chip holds
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lp = lane & 31;  // column of S^T, row of O
@@ -246,25 +254,57 @@ void prefill_mfma32_kernel(PrefillArgs a) {
 #pragma unroll
     for (int j = 0; j < DPW; ++j) off[j] = (uint32_t)ent[2 * j];
   };
-  auto issue_step = [&](int step) {
-    const uint32_t stage = lds_ring + (uint32_t)(step % NSTAGE) * STEP_BYTES;
+  // A step's requests of this wave: the four source addresses are made ahead of the wait and the
+  // barrier of the step that issues them (make_src), and the requests then go out as ONE statement,
+  // M0 set per request and restored once (four statements with their address arithmetic in between:
+  // 78 cycles per request, this form 54).
+  constexpr int NREQ = (BSGL_CUT & 64) ? DPW / 2 : DPW;
+  uint64_t src4[DPW];
+  auto make_src = [&]() {
 #pragma unroll
     for (int j = 0; j < DPW; ++j) {
-      const int i = wave * DPW + j;  // wave-uniform
-      const int t0 = 2 * (i & 7);
-      const uint32_t rec = (uint32_t)rec_of_token(t0);
-      const uint32_t xr = (uint32_t)xr_of_rec((int)rec);
-      uint64_t src = ((uint64_t)off[j] << 4) + lane_src;
-      src ^= (uint64_t)(xr << 4);
-      dma_1k<false>((const void*)src,
-                    __builtin_amdgcn_readfirstlane(stage + (uint32_t)(i >> 3) * TILE_BYTES + rec * REC));
+      const int i = wave * DPW + j;  // wave-uniform: request i brings tokens 2i, 2i+1 of the step (tile i / 8)
+      const uint32_t xr = (uint32_t)xr_of_rec(rec_of_token(2 * (i & 7)));
+      src4[j] = (((uint64_t)off[j] << 4) + lane_src) ^ (uint64_t)(xr << 4);
+    }
+  };
+  auto issue_step = [&](int step) {
+    static_assert(DPW == 4, "one statement of four requests");
+    const uint32_t stage = lds_ring + (uint32_t)(step % NSTAGE) * STEP_BYTES;
+    uint32_t dst[DPW];
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) {
+      const int i = wave * DPW + j;
+      dst[j] = __builtin_amdgcn_readfirstlane(stage + (uint32_t)(i >> 3) * TILE_BYTES + (uint32_t)rec_of_token(2 * (i & 7)) * REC);
+    }
+    uint32_t keep;
+    if constexpr (NREQ == DPW) {
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+          "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+          "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+          "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(src4[0]), "v"(src4[1]), "v"(src4[2]), "v"(src4[3]), "s"(dst[0]), "s"(dst[1]), "s"(dst[2]), "s"(dst[3])
+          : "memory");
+    } else {
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+          "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(src4[0]), "v"(src4[1]), "s"(dst[0]), "s"(dst[1])
+          : "memory");
     }
   };
 
   if (PROF) prof[5] += (__builtin_readcyclecounter() - t_stage) << 32;
-  if (n_steps > 0) { read_offsets(0); issue_step(0); }
-  if (n_steps > 1) { read_offsets(1); issue_step(1); }
-  if (n_steps > 2) { read_offsets(2); issue_step(2); }
+  if (n_steps > 0) { read_offsets(0); make_src(); issue_step(0); }
+  if (n_steps > 1) { read_offsets(1); make_src(); issue_step(1); }
+  if (n_steps > 2) { read_offsets(2); make_src(); issue_step(2); }
   if (n_steps > 3) read_offsets(3);
 
   // raw scores of the step about to be consumed and of the one after it: the two trade places
@@ -314,12 +354,14 @@ void prefill_mfma32_kernel(PrefillArgs a) {
       // for step 16 b + 16, requested in step 16 b + 13
       const int in_blk = step & (SLOTS / STEP - 1);
       const bool more_entries = ((step >> 4) + 1) * SLOTS < kv_len;  // wave-uniform
+      const bool issue_ok = ((BSGL_CUT & 4) == 0) && has_next && step + 3 < n_steps;  // wave-uniform
+      if (issue_ok) make_src();  // the addresses of this step's requests, ahead of the wait
       if (has_next) {
         // this wave's share of step + 1 has landed (one younger step may stay in flight, and in
         // step 16 b + 3 the two entry loads behind it) ...
         if (step + 2 >= n_steps) dma_wait<0>();
-        else if (in_blk == 3 && more_entries) dma_wait<DPW + 2>();
-        else dma_wait<DPW>();
+        else if (in_blk == 3 && more_entries) dma_wait<NREQ + 2>();
+        else dma_wait<NREQ>();
         t1 = PROF ? __builtin_readcyclecounter() : 0;
         if (in_blk == 4 && more_entries) {
           // (this wave's own two pieces, landed by the wait above; the barrier below publishes them)
@@ -331,8 +373,11 @@ void prefill_mfma32_kernel(PrefillArgs a) {
         // ... and so has everybody's; all waves are also done reading step - 1
         __syncthreads();
         t2 = PROF ? __builtin_readcyclecounter() : 0;
-        if (step + 3 < n_steps) issue_step(step + 3);  // into the stage step - 1 used
-        if (step + 4 < n_steps) read_offsets(step + 4);
+        // the row offsets of step + 4 are asked for first (any entries if there is no such step: they
+        // are then never used) and travel while this step's requests go out (read behind the requests,
+        // the wave waited for them before it could ask for its K fragments: 100 cycles per step)
+        read_offsets(step + 4);
+        if (issue_ok) issue_step(step + 3);  // into the stage step - 1 used
         if (in_blk == 2 && more_entries) {
           const int e = ((step >> 4) + 1) * SLOTS + tid;
           const uint32_t half = lds_slots + (uint32_t)((((step >> 4) + 1) & 1) * SLOTS * 4) + (uint32_t)wave * 256u;
@@ -403,16 +448,22 @@ void prefill_mfma32_kernel(PrefillArgs a) {
 #pragma unroll
       for (int kb = 0; kb < 8; ++kb) {
         sn = Mma32<Tag>::mm(kf[kb], qf[kb], sn);
-        p[2 * kb] = fast_exp2(e[2 * kb]);
-        p[2 * kb + 1] = fast_exp2(e[2 * kb + 1]);
-        if (kb < 7) {
-          e[2 * kb + 2] = fmaf(sc[2 * kb + 2], scale_log2e, neg_mc);
-          e[2 * kb + 3] = fmaf(sc[2 * kb + 3], scale_log2e, neg_mc);
+        if constexpr ((BSGL_CUT & 8) != 0) {  // timing cut: no exponentials, no multiply-adds
+          p[2 * kb] = sc[2 * kb];
+          p[2 * kb + 1] = sc[2 * kb + 1];
+        } else {
+          p[2 * kb] = fast_exp2(e[2 * kb]);
+          p[2 * kb + 1] = fast_exp2(e[2 * kb + 1]);
+          if (kb < 7) {
+            e[2 * kb + 2] = fmaf(sc[2 * kb + 2], scale_log2e, neg_mc);
+            e[2 * kb + 3] = fmaf(sc[2 * kb + 3], scale_log2e, neg_mc);
+          }
         }
         if (kb >= 4) pw[kb - 4] = E::pack2(p[2 * (kb - 4)], p[2 * (kb - 4) + 1]);
         if (kb >= 5) vf[kb - 5] = v_frag(kb - 5);
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (PROF) prof[4] += __builtin_readcyclecounter() - t3;  // the score half of the body
       // k-values of a lane in PV product i: registers 8 kk .. 8 kk + 7 of the score accumulator,
       // i.e. tokens {0-3, 8-11} + 4 hi of tile kk = i >> 2
 #pragma unroll
@@ -423,13 +474,15 @@ void prefill_mfma32_kernel(PrefillArgs a) {
         if (i < 4) pw[4 + i] = E::pack2(p[8 + 2 * i], p[8 + 2 * i + 1]);
         // (as instructions of their own, here: the compiler otherwise pairs the sums into packed adds
         // and parks them at the head of the next step)
-        asm volatile("v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2" : "+v"(l_run) : "v"(p[2 * i]), "v"(p[2 * i + 1]));
-        // (the next step's scores are complete by now: their largest, two maxima per gap)
-        if (i == 2) { mx0 = fmaxf(sn[0], sn[1]); mx1 = fmaxf(sn[2], sn[3]); }
-        if (i == 3) { mx0 = fmaxf(fmaxf(sn[4], sn[5]), mx0); mx1 = fmaxf(fmaxf(sn[6], sn[7]), mx1); }
-        if (i == 4) { mx0 = fmaxf(fmaxf(sn[8], sn[9]), mx0); mx1 = fmaxf(fmaxf(sn[10], sn[11]), mx1); }
-        if (i == 5) { mx0 = fmaxf(fmaxf(sn[12], sn[13]), mx0); mx1 = fmaxf(fmaxf(sn[14], sn[15]), mx1); }
-        if (i == 6) lmax_nx = fmaxf(mx0, mx1);
+        if constexpr ((BSGL_CUT & 8) == 0) {
+          asm volatile("v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2" : "+v"(l_run) : "v"(p[2 * i]), "v"(p[2 * i + 1]));
+          // (the next step's scores are complete by now: their largest, two maxima per gap)
+          if (i == 2) { mx0 = fmaxf(sn[0], sn[1]); mx1 = fmaxf(sn[2], sn[3]); }
+          if (i == 3) { mx0 = fmaxf(fmaxf(sn[4], sn[5]), mx0); mx1 = fmaxf(fmaxf(sn[6], sn[7]), mx1); }
+          if (i == 4) { mx0 = fmaxf(fmaxf(sn[8], sn[9]), mx0); mx1 = fmaxf(fmaxf(sn[10], sn[11]), mx1); }
+          if (i == 5) { mx0 = fmaxf(fmaxf(sn[12], sn[13]), mx0); mx1 = fmaxf(fmaxf(sn[14], sn[15]), mx1); }
+          if (i == 6) lmax_nx = fmaxf(mx0, mx1);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       if (PROF) prof[3] += __builtin_readcyclecounter() - t3;
@@ -474,8 +527,9 @@ void prefill_mfma32_kernel(PrefillArgs a) {
     }
   }
   if (PROF && lane == 0) {
-    prof[7] = __builtin_readcyclecounter() - t_entry;
+    prof[7] = (__builtin_readcyclecounter() - t_entry) & 0xffffffffu;
     prof[6] |= (uint64_t)(prof[7] - (t_loop_end - t_entry)) << 32;
+    prof[7] |= ((__builtin_amdgcn_s_memrealtime() - rt_entry) & 0xffffffffu) << 32;
     uint64_t* dst = a.prof + 8 * ((uint64_t)blockIdx.x * WAVES + wave);
 #pragma unroll
     for (int i = 0; i < 8; ++i) dst[i] = prof[i];

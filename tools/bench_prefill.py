@@ -98,22 +98,27 @@ def main():
         pkg._hip.lib.bsgl_debug_prefill_profile(None)
         ti = buf.cpu()
         ti = ti[ti[:, 7] > 0]
+        ticks = (ti[:, 7] >> 32).double()  # 100 MHz ticks of the wave's life (0 from kernels that do not stamp them)
+        ti[:, 7] &= 0xFFFFFFFF
         t = ti.double()
         staging = (ti[:, 5] >> 32).double()
         t[:, 5] = (ti[:, 5] & 0xFFFFFFFF).double()
         steps = t[:, 5].sum()
         names = ("own-DMA wait", "barrier", "DMA issue", "score+softmax (32x32x16 kernel: whole step body)", "PV (16x16x32 kernel only)")
-        tot = t[:, :5].sum()
+        ncol = 4 if ticks.sum() > 0 else 5  # (the 32x32x16 kernel's column 4 is a part of its column 3)
+        tot = t[:, :ncol].sum()
         print(f"  {len(t)} waves, {int(steps)} wave-steps; cycles per wave-step by phase:")
-        for i, n in enumerate(names):
+        for i, n in enumerate(names[:ncol]):
             print(f"    {n:50s} {t[:, i].sum() / steps:8.0f}  ({t[:, i].sum() / tot:6.1%})")
         print(f"    {'sum':50s} {tot / steps:8.0f}")
+        if ticks.sum() > 0:
+            print(f"    clock while the waves ran: {t[:, 7].sum() / ticks.sum() / 10:.3f} GHz; score half of the body {t[:, 4].sum() / steps:.0f} cycles")
         pro = ti[:, 6] & 0xFFFFFFFF
         epi = ti[:, 6] >> 32
         life = t[:, 7]
         print(f"  per wave: whole life {life.mean():.0f} cycles = before the first page-table read {pro.double().mean():.0f} "
-              f"+ staging the entries {staging.mean():.0f} + steps {t[:, :5].sum(1).mean():.0f} + after the last step {epi.double().mean():.0f} "
-              f"+ rest {life.mean() - pro.double().mean() - staging.mean() - t[:, :5].sum(1).mean() - epi.double().mean():.0f}")
+              f"+ staging the entries {staging.mean():.0f} + steps {t[:, :ncol].sum(1).mean():.0f} + after the last step {epi.double().mean():.0f} "
+              f"+ rest {life.mean() - pro.double().mean() - staging.mean() - t[:, :ncol].sum(1).mean() - epi.double().mean():.0f}")
 
 
 if __name__ == "__main__":
