@@ -11,6 +11,12 @@ one KV slab pair per layer, random-permutation page table (worst-case scatter).
   python bench.py [--gpus N --steps K --warmup W]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
+Typed without a launcher (``WORLD_SIZE`` unset) and ``--gpus N > 1``, it starts the N ranks itself
+(``self_launch``): N fresh child processes with the ``RANK`` / ``LOCAL_RANK`` / ``WORLD_SIZE`` /
+``MASTER_ADDR`` / ``MASTER_PORT`` environment that ``init_tp`` reads (reference: tp_runtime.py:10-25),
+started before this process has touched the GPU; rank 0's JSON line is forwarded, and the exit code
+is non-zero when any rank fails or the job outlives its watchdog.
+
 Prints ONE JSON line (rank 0).  ``value`` is decode tokens/s of the whole job
 with every input resident in HBM.  ``roofline`` prices the dominant kernel (the
 split-KV decode kernel) against HBM bandwidth with algorithmic bytes;
@@ -23,6 +29,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 import types
@@ -65,10 +73,73 @@ def parse_args():
                          "gather equals torch.distributed's, torch otherwise")
     ap.add_argument("--tp-graph", action="store_true",
                     help="N > 1 with capi collectives: replay the whole step, collectives included, from one HIP graph")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="N > 1 started without a launcher: seconds the ranks this process starts may run before they are ended")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1 GPUs: weak = N x batch requests over the tensor-parallel group (per-GPU KV bytes fixed), "
                          "strong = the same batch cut N ways")
     return ap.parse_args()
+
+
+def self_launch(n_ranks, child_argv=None, timeout_s=1500.0, poll_s=0.2, out=None, local_ranks=None):
+    """Start ``n_ranks`` fresh processes of this program with the environment a launcher would give
+    them (``RANK``, ``LOCAL_RANK``, ``WORLD_SIZE``, ``MASTER_ADDR=127.0.0.1``, a free ``MASTER_PORT``),
+    forward what rank 0 writes to its standard output to ``out`` and return the job's exit code:
+    0 when every rank exited 0; the first failing rank's code (the other ranks are ended at once, so
+    that nobody waits in a collective for a peer that is gone); 124 when the ranks outlive
+    ``timeout_s`` (all are ended).  The calling process must not have initialised the GPU."""
+    out = out if out is not None else sys.stdout
+    if child_argv is None:
+        child_argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    if local_ranks is None:
+        local_ranks = list(range(n_ranks))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                LOCAL_WORLD_SIZE=str(n_ranks), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    try:
+        for r in range(n_ranks):
+            env = dict(base, RANK=str(r), LOCAL_RANK=str(local_ranks[r]))
+            # rank 0's standard output carries the JSON line; the other ranks print nothing there
+            procs.append(subprocess.Popen(child_argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+        os.set_blocking(procs[0].stdout.fileno(), False)
+        deadline = time.monotonic() + timeout_s
+        rc = None
+        while rc is None:
+            chunk = procs[0].stdout.read()
+            if chunk:
+                out.write(chunk.decode("utf-8", "replace"))
+                out.flush()
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = bad[0] if bad[0] > 0 else 128 - bad[0]  # (a rank ended by signal n: 128 + n)
+            elif all(c == 0 for c in codes):
+                rc = 0
+            elif time.monotonic() > deadline:
+                print(f"bench.py: the {n_ranks} ranks did not finish within {timeout_s:.0f} s; ending them", file=sys.stderr)
+                rc = 124
+            else:
+                time.sleep(poll_s)
+        if rc == 0:
+            rest = procs[0].stdout.read()
+            if rest:
+                out.write(rest.decode("utf-8", "replace"))
+                out.flush()
+        return rc
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
 
 
 class Workload:
@@ -488,6 +559,22 @@ def parallelism_label(world, n_replicas, tp, layout):
 
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # typed without a launcher: this process only starts the ranks (it never touches the GPU;
+        # counting the devices does not initialise it)
+        n_dev = torch.cuda.device_count()
+        gloo = os.getenv("BABYSGL_TP_BACKEND") == "gloo"
+        if n_dev < args.gpus and not (gloo and n_dev >= 1):
+            raise SystemExit(f"--gpus {args.gpus}: {n_dev} GPU(s) visible and RCCL wants one per rank "
+                             "(BABYSGL_TP_BACKEND=gloo rehearses several ranks on fewer GPUs)")
+        local = [r if n_dev >= args.gpus else r % n_dev for r in range(args.gpus)]
+        import signal
+
+        def ended(signum, frame):  # SIGTERM to this process ends its ranks too (self_launch's clean-up runs)
+            raise SystemExit(128 + signum)
+
+        signal.signal(signal.SIGTERM, ended)
+        sys.exit(self_launch(args.gpus, timeout_s=args.launch_timeout, local_ranks=local))
     # stdout carries the ONE JSON line and nothing else: RCCL prints a five-line version banner on
     # stdout when a communicator comes up (every rank), so file descriptor 1 is pointed at stderr
     # for the run and the line goes out through a copy of the original descriptor.
@@ -496,8 +583,6 @@ def main():
     os.dup2(2, 1)
     world = int(os.getenv("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         args.gpus = world
     import baby_sglang_amd as pkg
 

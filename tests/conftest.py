@@ -24,6 +24,11 @@ TP_PROC_JOBS = {
     "tp_model_one_shot": ("tp_model_procs.py", 2, {"BABYSGL_P2P_ALLREDUCE": "1"}),
     "one_shot_all_reduce": ("p2p_procs.py", 4, {}),
 }
+# programs that start their own ranks: job name -> (argv after the interpreter, extra environment); no rank environment
+SELF_LAUNCH_JOBS = {
+    "bench_two_ranks": (["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-extras",
+                         "--launch-timeout", "150"], {"BABYSGL_TP_BACKEND": "gloo"}),
+}
 TP_PROCS = {}  # filled by pytest_sessionstart: job name -> {"procs": [Popen...], "logs": [path...]}
 
 
@@ -70,12 +75,25 @@ def pytest_sessionstart(session):
             job["logs"].append(log)
 
 
+    for name, (argv, extra) in SELF_LAUNCH_JOBS.items():
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
+        log, err = os.path.join(tmp, f"{name}.out"), os.path.join(tmp, f"{name}.err")
+        with open(log, "wb") as f, open(err, "wb") as e:
+            p = subprocess.Popen([sys.executable, os.path.join(ROOT, argv[0])] + argv[1:], env=env, stdout=f, stderr=e, cwd=ROOT)
+        TP_PROCS[name] = {"procs": [p], "logs": [log, err]}
+
+
 def pytest_sessionfinish(session, exitstatus):
     for job in TP_PROCS.values():
         for p in job["procs"]:
             if p.poll() is None:
-                p.kill()
-                p.wait()
+                p.terminate()  # (a program that started ranks of its own ends them on SIGTERM)
+                try:
+                    p.wait(timeout=15)
+                except Exception:  # noqa: BLE001
+                    p.kill()
+                    p.wait()
 
 
 def golden_names(prefix):

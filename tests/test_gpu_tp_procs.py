@@ -8,7 +8,10 @@ the tests here wait for their exit codes and verdict lines.
   row-parallel outputs summed with tp_all_reduce_sum, logits against the reference model's unsharded
   ones (reference: tp_runtime.py:10-33, qwen2.py:179-197) -- once with gloo's sums, once with the
   library's one-shot all-reduce through windows mapped by IPC handles;
-* tools/p2p_procs.py, four ranks: that all-reduce by itself over dtypes and sizes, bit for bit."""
+* tools/p2p_procs.py, four ranks: that all-reduce by itself over dtypes and sizes, bit for bit;
+* bench.py typed as ``python bench.py --gpus 2`` with no launcher around it: it starts its two ranks
+  itself (over gloo here, one GPU) and prints ONE line for one tensor-parallel group of two."""
+import json
 import subprocess
 
 import pytest
@@ -52,3 +55,25 @@ def test_one_shot_all_reduce_between_four_processes(gpu):
     logs, report = _verdicts("one_shot_all_reduce")
     for r, log in enumerate(logs):
         assert f"rank {r}/{len(logs)}:" in log and "equal the rank-ordered fp32 sum bit for bit" in log, report
+
+
+def test_bench_starts_its_own_ranks(gpu):
+    job = TP_PROCS.get("bench_two_ranks")
+    if not job:
+        pytest.skip("the job is only started when this file (or its directory) is run with -m gpu")
+    p = job["procs"][0]
+    try:
+        code = p.wait(timeout=200)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        code = "timeout"
+    with open(job["logs"][0], errors="replace") as f:
+        out = f.read()
+    with open(job["logs"][1], errors="replace") as f:
+        err = f.read()
+    assert code == 0, f"exit {code}\n{err[-3000:]}"
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1, out
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0
+    assert "ONE tensor-parallel group" in line["config"]["parallelism"] and "tp2" in line["config"]["parallelism"]
