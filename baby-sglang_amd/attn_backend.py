@@ -36,16 +36,22 @@ class SimpleAttentionBackend:
     # decode kernel selection: _hip.DECODE_AUTO picks the matrix-core kernel
     # when it covers the shape, the generic kernel otherwise
     decode_variant = _hip.DECODE_AUTO
-    # Decode steps hand the new token's K/V rows to the decode kernel, which
-    # stores them itself instead of a separate scatter launch.  Valid because
-    # the scheduler gives every decode token a fresh slot that only its own
-    # request's page-table row names (scheduler.py:459-490); set to False to
-    # keep the write a launch of its own.
+    # A decode step's new K/V rows can be stored by the decode kernel itself instead of a scatter
+    # launch ahead of it (2.8 us per layer).  That is only right when every slot in out_cache_loc is
+    # fresh: named by its own request's page-table row alone.  Otherwise a request whose row names
+    # ANOTHER request's new slot would read that row while it is being written; the reference
+    # writes all new rows before any request reads (attn_backend.py:20-23).  So the kernel only
+    # stores the rows for batches whose producer says so (SimplifiedForwardBatch.private_decode_slots;
+    # this package's ServingLoop does), or when the integrator vouches for every batch with
+    # ``assume_private_decode_slots`` (the reference's scheduler gives every decode token a fresh
+    # slot, scheduler.py:459-490, but its batch descriptor cannot say so).  ``fuse_decode_kv_write``
+    # = False keeps the write a launch of its own whatever the batch says.
     fuse_decode_kv_write = True
-    # Debug aid for that assumption (BABYSGL_CHECK_FUSED_KV=1, or set the attribute): before every
-    # decode call that fuses the write, check on the device -- with a host read, so not for
+    assume_private_decode_slots = False
+    # Debug aid for a producer's promise (BABYSGL_CHECK_FUSED_KV=1, or set the attribute): before
+    # every decode call that fuses the write, check on the device -- with a host read, so not for
     # production -- that no slot in out_cache_loc is named by ANOTHER request's visible page-table
-    # entries (or twice in out_cache_loc); a caller that breaks the rule gets a ValueError
+    # entries (or twice in out_cache_loc); a producer that breaks its word gets a ValueError
     # instead of silently wrong numbers.
     check_fused_kv_invariant = os.getenv("BABYSGL_CHECK_FUSED_KV", "0") not in ("", "0")
     # one zero-initialised decode workspace per (device, stream): calls on
@@ -118,8 +124,8 @@ class SimpleAttentionBackend:
             bad = hits.nonzero()[:4].tolist()
             raise ValueError(
                 "fuse_decode_kv_write: a slot in out_cache_loc is named by another request's page-table row "
-                f"(new slot of request i, named by request j: {bad}; duplicate slots: {dup}); set "
-                "SimpleAttentionBackend.fuse_decode_kv_write = False for such batches"
+                f"(new slot of request i, named by request j: {bad}; duplicate slots: {dup}); such a batch "
+                "must not set private_decode_slots"
             )
 
     # (pool, layer, batch, q heads, dtype, page table) -> a filled-in _hip.DecodeCall: everything
@@ -208,7 +214,7 @@ class SimpleAttentionBackend:
             if len(shape) != 3 or shape != v.shape or ks[1:] != (shape[2], 1) or vs[1:] != (shape[2], 1) \
                     or shape[0] != c.batch or shape[1] != c.n_kv_heads or shape[2] != c.head_dim:
                 return None
-            if SimpleAttentionBackend.fuse_decode_kv_write:
+            if SimpleAttentionBackend._fuses(forward_batch):
                 variant |= _hip.DECODE_FUSE_KV_WRITE
             out = torch.empty((shape[0], row), dtype=q.dtype, device=q.device)
             # the ten leading fields of the descriptor in one write: out, its row stride, lse, q, its
@@ -232,8 +238,15 @@ class SimpleAttentionBackend:
         return out
 
     @staticmethod
+    def _fuses(forward_batch) -> bool:
+        """Whether the decode kernel may store this batch's new rows itself."""
+        cls = SimpleAttentionBackend
+        return cls.fuse_decode_kv_write and (cls.assume_private_decode_slots or getattr(forward_batch, "private_decode_slots", False))
+
+    @staticmethod
     def _decode_attention(q, k, v, forward_batch: SimplifiedForwardBatch, layer_id: int):
-        if k is not None and SimpleAttentionBackend.fuse_decode_kv_write and SimpleAttentionBackend.check_fused_kv_invariant:
+        fuses = k is not None and SimpleAttentionBackend._fuses(forward_batch)
+        if fuses and SimpleAttentionBackend.check_fused_kv_invariant:
             SimpleAttentionBackend._check_fused_kv(forward_batch)
         out = SimpleAttentionBackend._decode_fast(q, k, v, forward_batch, layer_id)
         if out is not None:
@@ -257,7 +270,7 @@ class SimpleAttentionBackend:
             k_new=k,
             v_new=v,
             out_cache_loc=forward_batch.out_cache_loc if k is not None else None,
-            fuse_kv_write=SimpleAttentionBackend.fuse_decode_kv_write,
+            fuse_kv_write=fuses,
             _plan=plan,
         )
 

@@ -41,6 +41,13 @@ class SimplifiedForwardBatch:
     # launch; results never depend on it.
     max_seq_len: int = 0
 
+    # Not in the reference: the producer's word, for a decode batch, that every slot in out_cache_loc
+    # is fresh -- named by its own request's page-table row (at position seq_len - 1) and by nothing
+    # else, and by no other entry of out_cache_loc.  The backend then lets the decode kernel store the
+    # new rows itself; without it the rows are written by a launch of their own before attention reads
+    # the cache, which is right for any page table (reference order: attn_backend.py:20-23).
+    private_decode_slots: bool = False
+
     @classmethod
     def create_prefill_batch(
         cls,

@@ -501,6 +501,9 @@ class ServingLoop:
             token_to_kv_pool=self.token_to_kv_pool,
         )
         fb.max_seq_len = max(s.seq_len for s in batch)  # (known here without asking the device)
+        # every new slot comes straight from the free list and is written into its own request's row
+        # only; a slot the prefix tree shares is never a decode step's new slot
+        fb.private_decode_slots = True
         return fb
 
     # ---------------------------------------------------------------------------- results

@@ -218,6 +218,8 @@ class Workload:
             torch.zeros(self.args.batch, dtype=torch.int64, device=self.dev), self.req, self.local_seq,
             self.loc, self.r2t, self.kv,
         )
+        # (every synthetic table but "pairs" gives each request a last slot of its own)
+        self.fb.private_decode_slots = kind != "pairs"
 
     def v_rows(self, layer):
         c0 = (self.hq_l + self.hkv_l) * self.dim

@@ -32,6 +32,7 @@ def test_decode_step_replayed_on_new_inputs(gpu, dtype, hq, hkv, dim, seq_lens):
     loc = r2t.req_to_token[rows, seq - 1].contiguous()  # the step's new token sits in each request's last slot
     layer = types.SimpleNamespace(layer_id=0, scaling=dim**-0.5)
     fb = pkg.SimplifiedForwardBatch.create_decode_batch(torch.zeros(n, dtype=torch.int64, device=gpu), rows, seq, loc, r2t, kv)
+    fb.private_decode_slots = True  # (each request's last slot is its own: the decode kernel stores the new rows)
     q = torch.empty((n, hq, dim), dtype=dtype, device=gpu)
     k = torch.empty((n, hkv, dim), dtype=dtype, device=gpu)
     v = torch.empty((n, hkv, dim), dtype=dtype, device=gpu)

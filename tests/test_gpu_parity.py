@@ -42,8 +42,9 @@ def assert_close(got, want64, dtype, what=""):
         )
 
 
-def product_forward(case, dev, layout="interleaved", variant=None):
-    """Run one golden case through the product backend on the GPU."""
+def product_forward(case, dev, layout="interleaved", variant=None, private_slots=False):
+    """Run one golden case through the product backend on the GPU (``private_slots``: the batch says
+    that its new slots are fresh, so that the decode kernel stores the new rows itself)."""
     import baby_sglang_amd as pkg
 
     hkv, dim = case["n_kv_heads"], case["head_dim"]
@@ -66,6 +67,7 @@ def product_forward(case, dev, layout="interleaved", variant=None):
         fb = pkg.SimplifiedForwardBatch.create_prefill_batch(prefix_lens=case["prefix_lens"].to(dev), **common)
     else:
         fb = pkg.SimplifiedForwardBatch.create_decode_batch(**common)
+        fb.private_decode_slots = private_slots
     layer = types.SimpleNamespace(layer_id=layer_id, scaling=dim**-0.5)
     old = pkg.SimpleAttentionBackend.decode_variant
     if variant is not None:
@@ -90,11 +92,14 @@ def oracle_exact(case):
 
 
 @pytest.mark.parametrize("layout", ["interleaved", "split"])
-@pytest.mark.parametrize("name", golden_names("decode_") + golden_names("prefill_"))
-def test_golden_cases(gpu, name, layout):
+@pytest.mark.parametrize("name,private_slots", [(n, False) for n in golden_names("decode_") + golden_names("prefill_")]
+                         + [(n, True) for n in golden_names("decode_")])
+def test_golden_cases(gpu, name, layout, private_slots):
+    """(decode cases twice: new rows written by a launch of their own -- the default, right for any
+    page table -- and by the decode kernel, as for a producer that vouches for fresh slots)"""
     case = load_golden(name)
     dtype = case["q"].dtype
-    out, k_slab, v_slab = product_forward(case, gpu, layout)
+    out, k_slab, v_slab = product_forward(case, gpu, layout, private_slots=private_slots)
     want, k_want, v_want = oracle_exact(case)
     assert out.dtype == dtype and tuple(out.shape) == tuple(case["out"].shape)
     assert_close(out, want, dtype, f"{name} vs float64 oracle")
@@ -105,9 +110,12 @@ def test_golden_cases(gpu, name, layout):
     assert torch.equal(k_slab.cpu(), k_want) and torch.equal(v_slab.cpu(), v_want)
 
 
-def test_scheduler_trace_on_gpu(gpu):
+@pytest.mark.parametrize("private_slots", [False, True])
+def test_scheduler_trace_on_gpu(gpu, private_slots):
     """Replay the reference scheduler's ForwardBatch sequence (prefix reuse,
-    recycled slots) through the product backend, one persistent pool."""
+    recycled slots) through the product backend, one persistent pool; as the bare drop-in
+    (new rows of a decode step written ahead of attention) and with the word that the reference's
+    scheduler could give but its descriptor cannot carry (fresh slots: the kernel stores them)."""
     import baby_sglang_amd as pkg
 
     tr = load_golden("sched_trace")
@@ -130,6 +138,7 @@ def test_scheduler_trace_on_gpu(gpu):
             fb = pkg.SimplifiedForwardBatch.create_prefill_batch(prefix_lens=b["prefix_lens"].to(gpu), **common)
         else:
             fb = pkg.SimplifiedForwardBatch.create_decode_batch(**common)
+            fb.private_decode_slots = private_slots
         out = pkg.SimpleAttentionBackend.forward(b["q"].to(gpu), b["k"].to(gpu), b["v"].to(gpu), layer, fb)
         assert (out.double().cpu() - b["out"].double()).abs().max().item() <= 1e-5, f"batch {step}"
         # every slot the scheduler has handed out so far holds the reference's bytes

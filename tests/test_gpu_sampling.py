@@ -57,9 +57,44 @@ def test_device_draws_stay_inside_the_kept_set_and_follow_the_generator(gpu):
     assert torch.equal(a, b)
 
 
+def test_a_page_table_that_names_another_requests_new_slot(gpu):
+    """Reference order: every new row is written before any request reads the cache
+    (attn_backend.py:20-23), so a request whose page-table row names ANOTHER request's new slot sees
+    that request's new row.  With default settings the backend gives exactly that (the new rows are
+    a launch of their own ahead of attention).  A producer that wrongly vouches for fresh slots
+    (``private_decode_slots``) is caught by the opt-in debug check."""
+    import types
+
+    import baby_sglang_amd as pkg
+    from oracle import attn_oracle as orc
+    from test_gpu_parity import assert_close, random_decode_problem
+
+    cpu, r2t, kv = random_decode_problem(gpu, torch.bfloat16, 12, 2, 128, [20, 30, 9], seed=2)
+    rows, seq = cpu["req_pool_indices"].to(gpu), cpu["seq_lens"].to(gpu)
+    loc = r2t.req_to_token[rows, seq - 1].contiguous()
+    r2t.req_to_token[rows[1], 3] = loc[0]  # request 1 also names request 0's new slot
+    fb = pkg.SimplifiedForwardBatch.create_decode_batch(torch.zeros(3, dtype=torch.int64, device=gpu), rows, seq, loc, r2t, kv)
+    assert fb.private_decode_slots is False
+    layer = types.SimpleNamespace(layer_id=0, scaling=128**-0.5)
+    gen = torch.Generator().manual_seed(3)
+    q = cpu["q"].to(gpu)
+    k = (4 * torch.randn((3, 2, 128), generator=gen)).to(torch.bfloat16)
+    v = (4 * torch.randn((3, 2, 128), generator=gen)).to(torch.bfloat16)
+    out = pkg.SimpleAttentionBackend.forward(q, k.to(gpu), v.to(gpu), layer, fb)
+    k_ref, v_ref = cpu["k_slab"].clone(), cpu["v_slab"].clone()
+    orc.kv_scatter_ref(k_ref, v_ref, loc.cpu(), k, v)
+    table = r2t.req_to_token.cpu()
+    want = orc.decode_exact(cpu["q"], k_ref, v_ref, table, cpu["req_pool_indices"], cpu["seq_lens"])
+    assert_close(out, want, torch.bfloat16, "aliased page table, default settings")
+    # (and the new row does matter to request 1: without it the answer is another one)
+    stale = orc.decode_exact(cpu["q"], cpu["k_slab"], cpu["v_slab"], table, cpu["req_pool_indices"], cpu["seq_lens"])
+    assert (want[1] - stale[1]).abs().max().item() > 0.05
+
+
 def test_fused_kv_write_invariant_check(gpu):
-    """The opt-in debug check of the decode backend: a batch in which one request's page-table
-    row names another request's new slot is refused; the scheduler-shaped batch passes."""
+    """The opt-in debug check of the decode backend: a batch that says its new slots are fresh
+    while one request's page-table row names another request's new slot is refused; the
+    scheduler-shaped batch passes."""
     import types
 
     import baby_sglang_amd as pkg
@@ -69,6 +104,7 @@ def test_fused_kv_write_invariant_check(gpu):
     rows, seq = cpu["req_pool_indices"].to(gpu), cpu["seq_lens"].to(gpu)
     loc = r2t.req_to_token[rows, seq - 1].contiguous()
     fb = pkg.SimplifiedForwardBatch.create_decode_batch(torch.zeros(3, dtype=torch.int64, device=gpu), rows, seq, loc, r2t, kv)
+    fb.private_decode_slots = True
     layer = types.SimpleNamespace(layer_id=0, scaling=128**-0.5)
     q = cpu["q"].to(gpu)
     k = torch.randn((3, 2, 128), device=gpu).to(torch.bfloat16)

@@ -40,6 +40,15 @@ def test_same_batches_as_the_reference_scheduler(name):
     seen = []
 
     def record(mode, fb):
+        if not fb.is_prefill:
+            # the loop vouches for fresh slots (the decode kernel may then store the new rows itself):
+            # each new slot is named once among the batch's visible page-table entries, by its own row
+            assert fb.private_decode_slots
+            table = fb.req_to_token_pool.req_to_token[fb.req_pool_indices]
+            visible = torch.arange(table.shape[1])[None, :] < fb.seq_lens[:, None]
+            for i, slot in enumerate(fb.out_cache_loc.tolist()):
+                hits = ((table == slot) & visible).nonzero().tolist()
+                assert hits == [[i, int(fb.seq_lens[i]) - 1]], (slot, hits)
         seen.append({
             "mode": mode, "input_ids": fb.input_ids.clone(), "positions": fb.positions.clone(),
             "req_pool_indices": fb.req_pool_indices.clone(), "seq_lens": fb.seq_lens.clone(),

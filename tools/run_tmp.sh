@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r3i
-timeout -k 10 600 python -u -m pytest tests/test_gpu_large_pool.py -x -v -m gpu --timeout 300 --timeout-method thread > gpurun_out/r3i/large.txt 2>&1; rc=$?
-tail -40 gpurun_out/r3i/large.txt | cut -c1-300
+mkdir -p gpurun_out/r3j
+timeout -k 10 900 python -u -m pytest tests -x -q -m gpu --timeout 300 --timeout-method thread > gpurun_out/r3j/gpu_tests.txt 2>&1; rc=$?
+tail -15 gpurun_out/r3j/gpu_tests.txt | cut -c1-300
 exit $rc
