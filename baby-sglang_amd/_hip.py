@@ -121,6 +121,7 @@ SIGNATURES = {
     "bsgl_p2p_connect": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp)]),
     "bsgl_p2p_all_reduce_sum": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "bsgl_p2p_status": (ctypes.c_int, [_vp, ctypes.POINTER(_i32), ctypes.POINTER(_i64)]),
+    "bsgl_p2p_status_async": (ctypes.c_int, [_vp, _vp, _vp]),
     "bsgl_p2p_destroy": (ctypes.c_int, [_vp]),
 }
 
@@ -642,6 +643,11 @@ class P2PComm:
         self.handle: bytes = handle.raw
         self.window: int = int(window.value)
         self._last_stream = None
+        # a status probe in flight: (event behind the copy, pinned {status, calls}); see all_reduce_sum
+        self._probe = None
+        self._probe_words = None
+        self._calls_since_probe = 0
+        self.probe_every = 64
 
     def connect(self, handles: Optional[list] = None, windows: Optional[list] = None) -> None:
         if (handles is None) == (windows is None):
@@ -663,17 +669,63 @@ class P2PComm:
                 and nbytes % 16 == 0 and x.data_ptr() % 16 == 0)
 
     def all_reduce_sum(self, x: torch.Tensor) -> torch.Tensor:
+        """In place on the caller's current stream.  Raises ``RuntimeError`` once a status probe has
+        shown that a peer did not arrive (``check`` below): after that the library skips every sum,
+        and a model that kept going would run on unsummed activations without a word."""
         _need_gpu(x)
         if not x.is_contiguous():
             raise ValueError("all_reduce_sum needs a contiguous tensor")
         stream = torch.cuda.current_stream(x.device)
-        if self._last_stream is not None and stream != self._last_stream:
+        capturing = torch.cuda.is_current_stream_capturing()
+        if self._last_stream is not None and stream != self._last_stream and not capturing:
             # the calls of a communicator run one after the other: a new stream waits for the last one
+            # (not while the new stream is being captured: a wait for work outside the capture is no
+            # legal capture operation, and the caller synchronises before it captures)
             stream.wait_stream(self._last_stream)
-        self._last_stream = stream
+        if not capturing:
+            self._last_stream = stream
+            self.check(wait=False)
         _check(lib.bsgl_p2p_all_reduce_sum(self._comm, x.data_ptr(), x.numel(), _dtype_code(x), stream.cuda_stream),
                "bsgl_p2p_all_reduce_sum")
+        if not capturing:
+            self._calls_since_probe += 1
+            if self._probe is None and self._calls_since_probe >= self.probe_every:
+                self._start_probe(stream)
         return x
+
+    def _start_probe(self, stream) -> None:
+        if self._probe_words is None:
+            self._probe_words = torch.zeros(2, dtype=torch.int32).pin_memory()
+        _check(lib.bsgl_p2p_status_async(self._comm, self._probe_words.data_ptr(), stream.cuda_stream), "bsgl_p2p_status_async")
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self._probe = ev
+        self._calls_since_probe = 0
+
+    def check(self, wait: bool = True) -> None:
+        """Look at the communicator's status word and raise ``RuntimeError`` if a peer did not arrive.
+        ``wait=False`` (what ``all_reduce_sum`` does on every eager call): only looks at a probe whose
+        copy has already finished -- a probe is enqueued every ``probe_every`` calls, so a failure is
+        noticed at most that many calls plus the depth of the stream late, and the hot path never
+        waits.  ``wait=True`` (a serving loop at the end of a step, a test): enqueues a probe if none
+        is in flight and waits for it."""
+        if self._comm is None:
+            return
+        if wait and self._probe is None:
+            self._start_probe(torch.cuda.current_stream())
+        if self._probe is None:
+            return
+        if wait:
+            self._probe.synchronize()
+        elif not self._probe.query():
+            return
+        self._probe = None
+        status, calls = int(self._probe_words[0]), int(self._probe_words[1])
+        if status != 0:
+            raise RuntimeError(
+                f"one-shot all-reduce: a peer did not arrive within the wait (status {status} after {calls} completed calls); "
+                "the buffer of that call is undefined and every later sum was skipped"
+            )
 
     def status(self):
         """``(status, completed calls)`` -- waits for the device; status 0 = good, 1 = a peer did not arrive."""

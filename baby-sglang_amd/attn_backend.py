@@ -23,6 +23,7 @@ Behaviour kept from the reference, deliberately:
 
 from __future__ import annotations
 
+import collections
 import os
 import threading
 
@@ -30,6 +31,40 @@ import torch
 
 from . import _hip
 from .forward_batch import SimplifiedForwardBatch
+
+
+class _PerStream:
+    """One buffer per (device, stream), at most ``keep`` of them: the least recently used entry goes
+    when a new stream shows up (a serving process has a main stream, a worker's side stream and
+    perhaps a capture stream; a process that keeps making streams must not keep a buffer for each).
+    A dropped buffer's memory goes back to torch's allocator, which hands it out again in the order
+    of the stream it was allocated on -- the stream whose calls used it."""
+
+    def __init__(self, keep: int = 8):
+        self.keep = keep
+        self._items = collections.OrderedDict()
+        self._lock = threading.Lock()
+
+    def get(self, key, n_bytes: int, make):
+        with self._lock:
+            buf = self._items.get(key)
+            if buf is not None and buf.numel() >= n_bytes:
+                self._items.move_to_end(key)
+                return buf
+        buf = make(n_bytes)
+        with self._lock:
+            self._items[key] = buf
+            self._items.move_to_end(key)
+            while len(self._items) > self.keep:
+                self._items.popitem(last=False)
+        return buf
+
+    def __len__(self):
+        return len(self._items)
+
+    def clear(self):
+        with self._lock:
+            self._items.clear()
 
 
 class SimpleAttentionBackend:
@@ -56,8 +91,9 @@ class SimpleAttentionBackend:
     check_fused_kv_invariant = os.getenv("BABYSGL_CHECK_FUSED_KV", "0") not in ("", "0")
     # one zero-initialised decode workspace per (device, stream): calls on
     # different streams may overlap (overlap_worker.py:104-127) and must not
-    # share split-merge tickets
-    _workspaces = {}
+    # share split-merge tickets; likewise one extend workspace per stream
+    _workspaces = _PerStream()
+    _prefill_workspaces = _PerStream()
 
     @staticmethod
     def forward(
@@ -100,11 +136,8 @@ class SimpleAttentionBackend:
             SimpleAttentionBackend._plans[shape] = plan
         n_splits, need = plan
         stream = torch.cuda.current_stream(q.device).cuda_stream
-        key = (q.device, stream)
-        ws = SimpleAttentionBackend._workspaces.get(key)
-        if ws is None or ws.numel() < need:
-            ws = _hip.new_decode_workspace(max(need, 1 << 20), q.device)
-            SimpleAttentionBackend._workspaces[key] = ws
+        ws = SimpleAttentionBackend._workspaces.get(
+            (q.device, stream), need, lambda n: _hip.new_decode_workspace(max(n, 1 << 20), q.device))
         return n_splits, ws, (need, stream)
 
     @staticmethod
@@ -184,10 +217,12 @@ class SimpleAttentionBackend:
             return None
         c = rec[0]
         # what the batch brings, looked up once per step (the same object comes back for every layer)
+        # (the pointers are only good for the tensors they were taken from: a caller that reuses one
+        # batch object and binds new index tensors to it gets a new look-up, three identity compares)
         step = getattr(forward_batch, "_bsgl_step", None)
         stream = _hip.current_stream_handle(q.device.index)
-        if step is None or step[0] != stream:
-            rows, seq, loc = forward_batch.req_pool_indices, forward_batch.seq_lens, forward_batch.out_cache_loc
+        rows, seq, loc = forward_batch.req_pool_indices, forward_batch.seq_lens, forward_batch.out_cache_loc
+        if step is None or step[0] != stream or step[6] is not rows or step[7] is not seq or step[8] is not loc:
             if rows.dtype != torch.int64 or seq.dtype != torch.int64 or not rows.is_contiguous() or not seq.is_contiguous():
                 return None
             if rows.shape[0] != c.batch or seq.shape[0] != c.batch:
@@ -195,11 +230,9 @@ class SimpleAttentionBackend:
             loc_ptr = 0
             if loc is not None and loc.dtype == torch.int32 and loc.is_contiguous() and loc.shape[0] == c.batch:
                 loc_ptr = loc.data_ptr()
-            ws = SimpleAttentionBackend._workspaces.get((q.device, stream))
-            if ws is None or ws.numel() < c.workspace_bytes:
-                ws = _hip.new_decode_workspace(max(c.workspace_bytes, 1 << 20), q.device)
-                SimpleAttentionBackend._workspaces[(q.device, stream)] = ws
-            step = (stream, rows.data_ptr(), seq.data_ptr(), loc_ptr, ws.data_ptr(), ws)
+            ws = SimpleAttentionBackend._workspaces.get(
+                (q.device, stream), c.workspace_bytes, lambda n: _hip.new_decode_workspace(max(n, 1 << 20), q.device))
+            step = (stream, rows.data_ptr(), seq.data_ptr(), loc_ptr, ws.data_ptr(), ws, rows, seq, loc)
             try:
                 forward_batch._bsgl_step = step
             except AttributeError:  # (a batch object that takes no new attributes)
@@ -277,6 +310,13 @@ class SimpleAttentionBackend:
     @staticmethod
     def _prefill_attention(q, forward_batch: SimplifiedForwardBatch, layer_id: int):
         k_slab, v_slab = forward_batch.token_to_kv_pool.get_kv_buffer(layer_id)
+        workspace = None
+        if q.is_cuda and q.dim() == 3:
+            # the extend launch's work list lives in a per-stream buffer instead of a fresh allocation per layer call
+            need = _hip.prefill_workspace_bytes(int(forward_batch.req_pool_indices.shape[0]), q.shape[0], q.shape[1], q.shape[2])
+            stream = _hip.current_stream_handle(q.device.index)
+            workspace = SimpleAttentionBackend._prefill_workspaces.get(
+                (q.device, stream), need, lambda n: torch.empty(max(n, 1 << 16), dtype=torch.uint8, device=q.device))
         return _hip.paged_prefill(
             q,
             k_slab,
@@ -286,4 +326,5 @@ class SimpleAttentionBackend:
             forward_batch.seq_lens,
             forward_batch.prefix_lens,
             forward_batch.extended_lens,
+            workspace=workspace,
         )

@@ -360,13 +360,19 @@ constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mu;
 void* g_scratch_ptr[kMaxDevices] = {};
 
-int scratch_of_current_device(void** out) {
+// (`capturing`: the caller's stream is being captured.  The address is then only handed out if an
+// earlier, eager call on this device has looked it up: the first look-up loads the code object's
+// symbol table, which is no operation for a stream capture to run into.)
+int scratch_of_current_device(void** out, bool capturing) {
   int dev = -1;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return hip_fail("hipGetDevice", e);
   if (dev < 0 || dev >= kMaxDevices) return fail(BSGL_ERR_UNSUPPORTED, "device ordinal %d outside [0, %d)", dev, kMaxDevices);
   std::lock_guard<std::mutex> lock(g_scratch_mu);
   if (g_scratch_ptr[dev] == nullptr) {
+    if (capturing)
+      return fail(BSGL_ERR_UNSUPPORTED, "bsgl_paged_decode_static: first call on device %d while its stream is being captured; "
+                  "make one eager call on the device first (the warm-up run a capture needs anyway)", dev);
     void* p = nullptr;
     e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
     if (e != hipSuccess) return hip_fail("hipGetSymbolAddress(scratch)", e);
@@ -419,7 +425,10 @@ int decode_entry(void* out, int64_t out_row_stride, float* lse, const void* q, i
       return fail(BSGL_ERR_WORKSPACE, "bsgl_paged_decode_static: batch %d x %d q heads x %d splits needs %zu bytes of scratch, "
                   "the library's array holds %zu; use bsgl_paged_decode with a workspace, or fewer splits",
                   batch, n_q_heads, n_splits, need, kStaticScratchBytes);
-    if (int rc = scratch_of_current_device(&workspace)) return rc;
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    const hipError_t ec = hipStreamIsCapturing((hipStream_t)stream, &capturing);
+    if (ec != hipSuccess) return hip_fail("hipStreamIsCapturing", ec);
+    if (int rc = scratch_of_current_device(&workspace, capturing != hipStreamCaptureStatusNone)) return rc;
     workspace_bytes = kStaticScratchBytes;
     // The array keeps the last call's contents, and the tickets of this call's rows must start at
     // zero.  They do after every launch that ran to its end (the workgroup that merges a row stores
@@ -428,10 +437,11 @@ int decode_entry(void* out, int64_t out_row_stride, float* lse, const void* q, i
     // clearing is left out: as a memset node it was found not to be ordered in front of the kernel
     // node when the graph is replayed (ROCm 7.0 / 7.2: rows merged from stale partial results), and a
     // replayed graph starts from the zeros its own last replay, or the eager warm-up call, left.
-    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
-    const hipError_t ec = hipStreamIsCapturing((hipStream_t)stream, &capturing);
-    if (ec != hipSuccess) return hip_fail("hipStreamIsCapturing", ec);
+#ifdef BSGL_STATIC_MEMSET_IN_CAPTURE  // (probe build: the clearing as a memset node of the captured graph)
+    {
+#else
     if (capturing == hipStreamCaptureStatusNone) {
+#endif
       const size_t ticket_bytes = align_up((size_t)batch * (size_t)n_kv_heads * 4, 256);
       const hipError_t em = hipMemsetAsync(workspace, 0, ticket_bytes < kCounterBytes ? ticket_bytes : kCounterBytes, (hipStream_t)stream);
       if (em != hipSuccess) return hip_fail("hipMemsetAsync(scratch tickets)", em);

@@ -98,8 +98,14 @@ __global__ __launch_bounds__(kThreads) void p2p_all_reduce_kernel(Windows win, i
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, in[v]), own, v * 16, 0, kSys);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every byte of this wave has left
     __syncthreads();
-    if (tid == 0)
+    if (tid == 0) {
+      // system-scope release in front of the flag: the stores above are write-through already, the
+      // fence gives the same guarantee through the memory model instead of by hand (its own wait is
+      // written out: the compiler may drop the one it implies when it sees the counter at zero)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __hip_atomic_store(word(mine, (size_t)g * kFlagStride), call, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     // -- one lane per peer waits for that peer's chunk
     if (tid < world && tid != rank) {
       const uint32_t* flag = word(win.w[tid], (size_t)g * kFlagStride);
@@ -111,6 +117,12 @@ __global__ __launch_bounds__(kThreads) void p2p_all_reduce_kernel(Windows win, i
         }
         __builtin_amdgcn_s_sleep(8);
       }
+    }
+    if (tid < 64) {
+      // one relaxed poll per peer, then ONE system-scope acquire by the polling wave, waited for in
+      // front of the barrier that lets the other waves load (the loads below also bypass the caches)
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
     if (s_failed == 0) {
@@ -274,6 +286,16 @@ int bsgl_p2p_status(bsgl_p2p_comm* c, int32_t* status_out, int64_t* calls_out) {
   if (e != hipSuccess) return hip_fail("hipMemcpy(window status)", e);
   if (calls_out != nullptr) *calls_out = words[0];
   if (status_out != nullptr) *status_out = (int32_t)words[(kStatusOffset - kDoneOffset) / 4];
+  return BSGL_OK;
+}
+
+int bsgl_p2p_status_async(bsgl_p2p_comm* c, int32_t* host_words, void* stream) {
+  if (c == nullptr || host_words == nullptr) return fail(BSGL_ERR_BAD_ARG, "null communicator or host buffer%s");
+  // status word and call counter: two copies of 4 bytes behind the calls already enqueued on the stream
+  hipError_t e = hipMemcpyAsync(host_words, (const uint8_t*)c->window + kStatusOffset, 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(host_words + 1, (const uint8_t*)c->window + kDoneOffset, 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail("hipMemcpyAsync(window status)", e);
   return BSGL_OK;
 }
 

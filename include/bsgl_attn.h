@@ -374,6 +374,16 @@ int bsgl_comm_destroy(void);
  *                     call returns at once without touching `buf`.
  *   bsgl_p2p_status   copies the status (0 = good) and the number of completed calls to the host:
  *                     WAITS for the device; for set-up checks and tests, not for the serving loop.
+ *   bsgl_p2p_status_async  enqueues the copy of {status, completed calls} into `host_words` (two
+ *                     int32 of PINNED host memory) on `stream` and returns: the caller records an
+ *                     event behind it and looks at the words once the event has passed -- how a serving
+ *                     loop notices, a few steps late but without ever waiting, that a peer did not
+ *                     arrive (from then on every sum is skipped: keep going and the model runs on
+ *                     unsummed activations).  Not to be called while the stream is being captured.
+ *                     Between GPUs the protocol rests on fine-grained memory, system-scope
+ *                     release / acquire and cache-bypassing accesses as the ISA defines them; it has
+ *                     only ever run with all ranks on ONE GPU (no link in between): cross-device
+ *                     operation is unmeasured.
  *   bsgl_p2p_destroy  unmaps the peers' windows and frees the own one (after the peers are done).
  */
 #define BSGL_P2P_HANDLE_BYTES 64
@@ -387,6 +397,7 @@ int bsgl_p2p_connect(bsgl_p2p_comm* comm, const void* handles /*host, world x BS
 int bsgl_p2p_all_reduce_sum(bsgl_p2p_comm* comm, void* buf /*device, count elements, in place*/, int64_t count,
                             int32_t dtype, void* stream);
 int bsgl_p2p_status(bsgl_p2p_comm* comm, int32_t* status_out /*or NULL*/, int64_t* calls_out /*or NULL*/);
+int bsgl_p2p_status_async(bsgl_p2p_comm* comm, int32_t* host_words /*pinned host, 2 x int32*/, void* stream);
 int bsgl_p2p_destroy(bsgl_p2p_comm* comm);
 
 #ifdef __cplusplus

@@ -28,6 +28,8 @@ TP_PROC_JOBS = {
 SELF_LAUNCH_JOBS = {
     "bench_two_ranks": (["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0", "--no-extras",
                          "--launch-timeout", "150"], {"BABYSGL_TP_BACKEND": "gloo"}),
+    # needs a process in which the no-workspace decode entry point has never run
+    "static_first_call": (["tools/static_capture_first_call.py"], {}),
 }
 TP_PROCS = {}  # filled by pytest_sessionstart: job name -> {"procs": [Popen...], "logs": [path...]}
 

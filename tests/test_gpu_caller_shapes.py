@@ -127,3 +127,45 @@ def test_a_batch_that_names_its_longest_request(gpu):
         assert_close(out, want, dtype, f"hint {hint}")
         k_slab, v_slab = kv.get_kv_buffer(0)
         assert torch.equal(k_slab.cpu(), cpu["k_slab"]) and torch.equal(v_slab.cpu(), cpu["v_slab"])
+
+
+def test_one_batch_object_rebound_to_new_index_tensors(gpu):
+    """A caller may keep ONE batch object and bind new index tensors to it from step to step (the
+    dataclass is mutable; a static batch is a natural way to drive graph replays).  The backend keeps
+    the pointers it looked up on the batch object: they must be looked up again when the tensors are
+    other objects -- here the second step runs fewer tokens per request, from freshly made tensors,
+    after the first step's tensors are gone."""
+    import gc
+
+    import baby_sglang_amd as pkg
+
+    dtype, hq, hkv, dim = torch.bfloat16, 12, 2, 128
+    seq_lens = [900, 40, 1500, 7]
+    n = len(seq_lens)
+    cpu, r2t, kv = random_decode_problem(gpu, dtype, hq, hkv, dim, seq_lens, seed=11)
+    layer = types.SimpleNamespace(layer_id=0, scaling=dim**-0.5)
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn((n, hq, dim), generator=g).to(dtype)
+    rows = cpu["req_pool_indices"].to(gpu)
+    seq = cpu["seq_lens"].to(gpu)
+    loc = r2t.req_to_token[rows, seq - 1].contiguous()
+    fb = pkg.SimplifiedForwardBatch.create_decode_batch(torch.zeros(n, dtype=torch.int64, device=gpu), rows, seq, loc, r2t, kv)
+    out = pkg.SimpleAttentionBackend.forward(q.to(gpu), None, None, layer, fb)
+    want = orc.decode_exact(q, cpu["k_slab"], cpu["v_slab"], cpu["req_to_token"], cpu["req_pool_indices"], cpu["seq_lens"])
+    assert_close(out, want, dtype, "first step")
+    # second step on the SAME batch object: shorter requests, other rows first, all in new tensors
+    order = torch.tensor([2, 0, 3, 1])
+    seq2_cpu = (cpu["seq_lens"][order] // 2).clamp_min(1)
+    rows2_cpu = cpu["req_pool_indices"][order]
+    del rows, seq, loc
+    gc.collect()
+    torch.cuda.empty_cache()
+    junk = [torch.full((n,), 10**9, dtype=torch.int64, device=gpu) for _ in range(64)]  # (what freed index tensors may turn into)
+    fb.req_pool_indices = rows2_cpu.to(gpu)
+    fb.seq_lens = seq2_cpu.to(gpu)
+    fb.out_cache_loc = r2t.req_to_token[fb.req_pool_indices, fb.seq_lens - 1].contiguous()
+    fb.positions = fb.seq_lens - 1
+    out2 = pkg.SimpleAttentionBackend.forward(q.to(gpu), None, None, layer, fb)
+    want2 = orc.decode_exact(q, cpu["k_slab"], cpu["v_slab"], cpu["req_to_token"], rows2_cpu, seq2_cpu)
+    assert_close(out2, want2, dtype, "second step, rebound tensors")
+    del junk

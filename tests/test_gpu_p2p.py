@@ -174,6 +174,65 @@ def test_a_peer_that_never_arrives(gpu, knobs):
         torch.cuda.synchronize()
         assert time.perf_counter() - t0 < 0.25
         assert bool((y == 3.0).all()) and comms[0].status() == (1, 2)
+        # the wrapper tells its caller: a waited check raises, and so does the call that follows a
+        # finished status probe (a probe goes out every `probe_every` calls and is never waited for)
+        with pytest.raises(RuntimeError, match="a peer did not arrive"):
+            comms[0].check()
+        comms[0].probe_every = 2
+        with torch.cuda.stream(streams[0]):
+            comms[0].all_reduce_sum(y)
+            comms[0].all_reduce_sum(y)  # the second call enqueues the probe behind itself
+            torch.cuda.synchronize()
+            with pytest.raises(RuntimeError, match="a peer did not arrive"):
+                comms[0].all_reduce_sum(y)
+    finally:
+        for c in comms:
+            c.destroy()
+
+
+def test_eager_warm_up_then_capture_then_replay(gpu):
+    """The usual way to a graph: eager calls on the current stream first, then the capture (on the
+    capture's own stream), then replays.  The wrapper makes a new stream wait for the stream of the
+    communicator's last call -- but not while that new stream is being captured (a wait for work
+    outside the capture is no legal capture operation)."""
+    comms, streams = _make()
+    try:
+        n = 64 * 1536
+        bufs = [torch.zeros(n, dtype=torch.bfloat16, device=gpu) for _ in comms]
+
+        def run_eager(xs):
+            for b, x in zip(bufs, xs):
+                b.copy_(x)
+            torch.cuda.synchronize()
+            for c, s, b in zip(comms, streams, bufs):
+                with torch.cuda.stream(s):
+                    c.all_reduce_sum(b)
+            torch.cuda.synchronize()
+
+        xs = [torch.randn(n, device=gpu).to(torch.bfloat16) for _ in comms]
+        run_eager(xs)  # warm-up on the ranks' streams
+        for b in bufs:
+            assert torch.equal(b, _expected(xs))
+        graphs = []
+        for c, b in zip(comms, bufs):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):  # (a capture stream of torch's own: not the stream of the warm-up)
+                c.all_reduce_sum(b)
+            graphs.append(g)
+        for trial in range(2):
+            xs = [torch.randn(n, device=gpu).to(torch.bfloat16) for _ in comms]
+            for b, x in zip(bufs, xs):
+                b.copy_(x)
+            torch.cuda.synchronize()
+            for g, s in zip(graphs, streams):
+                with torch.cuda.stream(s):
+                    g.replay()
+            torch.cuda.synchronize()
+            for b in bufs:
+                assert torch.equal(b, _expected(xs)), trial
+        assert [c.status() for c in comms] == [(0, 3), (0, 3)]
+        for c in comms:
+            c.check()
     finally:
         for c in comms:
             c.destroy()

@@ -77,3 +77,22 @@ def test_bench_starts_its_own_ranks(gpu):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0
     assert "ONE tensor-parallel group" in line["config"]["parallelism"] and "tp2" in line["config"]["parallelism"]
+
+
+def test_no_workspace_decode_refuses_a_first_call_under_capture(gpu):
+    """tools/static_capture_first_call.py in a process of its own (in this one the entry point has
+    run already, or will have by the time a capture could be tried)."""
+    job = TP_PROCS.get("static_first_call")
+    if not job:
+        pytest.skip("the job is only started when this file (or its directory) is run with -m gpu")
+    p = job["procs"][0]
+    try:
+        code = p.wait(timeout=200)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        code = "timeout"
+    with open(job["logs"][0], errors="replace") as f:
+        out = f.read()
+    with open(job["logs"][1], errors="replace") as f:
+        err = f.read()
+    assert code == 0 and "first call refused, later capture replays right" in out, f"exit {code}\n{out[-1000:]}\n{err[-3000:]}"

@@ -151,3 +151,32 @@ def test_shard_state_dict_shapes():
             b = cut["l.self_attn.qkv_proj.qkv_proj.bias"]
             kv_head = rank * 2 // world
             assert b[0].item() == rank * hq_l * 128 and b[hq_l * 128].item() == (12 + kv_head) * 128 and b[(hq_l + 1) * 128].item() == (14 + kv_head) * 128
+
+
+def test_per_stream_buffers_are_bounded():
+    """The backend keeps one workspace per (device, stream) and drops the least recently used one
+    beyond a handful: a process that keeps making streams does not keep a buffer for each."""
+    from baby_sglang_amd.attn_backend import _PerStream
+
+    made = []
+
+    def make(n):
+        made.append(n)
+        return torch.zeros(n, dtype=torch.uint8)
+
+    cache = _PerStream(keep=3)
+    a = cache.get(("cpu", 1), 16, make)
+    assert cache.get(("cpu", 1), 8, make) is a and made == [16]  # big enough: the same buffer
+    assert cache.get(("cpu", 1), 32, make) is not a and made == [16, 32]  # too small: a new one replaces it
+    for stream in (2, 3):
+        cache.get(("cpu", stream), 16, make)
+    assert len(cache) == 3
+    cache.get(("cpu", 1), 8, make)  # stream 1 is the most recently used again
+    cache.get(("cpu", 4), 16, make)  # a fourth stream: the least recently used (2) goes
+    assert len(cache) == 3
+    n_made = len(made)
+    cache.get(("cpu", 1), 8, make)
+    cache.get(("cpu", 3), 8, make)
+    assert len(made) == n_made
+    cache.get(("cpu", 2), 8, make)
+    assert len(made) == n_made + 1
