@@ -20,10 +20,20 @@ What is arranged differently, for a GPU that should not wait on the host:
 Overlap mode (``run_batch_overlap``; reference: scheduler.py:599-761 with
 overlap_worker.py:27-160): the next batch is selected, built and launched while the
 previous one is still running, and a batch's sampled ids are looked at one step late.
-The reference does this with a worker thread on a second stream and negative
-placeholder ids resolved from a "future token" map; here one thread and one HIP stream
-do: sampled ids stay on the device in a per-row buffer that the next decode batch
-gathers its input ids from, every host-to-device copy of batch metadata goes through
+Two forms.  The reference's: a worker thread runs the model and the sampling on a second
+stream while the loop's own thread selects and builds the next batch on its stream
+(``overlap_worker=True``, the default on a GPU; ``_ForwardWorker`` below).  The batch's
+metadata copies are ordered in front of the worker's forward by an event the worker's
+stream waits for (the reference makes the host wait for the scheduler's stream instead,
+overlap_worker.py:83), the sampled ids stay on the device, and the loop looks at them one
+step late behind the event of their device-to-host copy (overlap_worker.py:155-160).
+Where the reference feeds the next step negative placeholder ids that its worker
+resolves from a "future token" map (overlap_worker.py:39-44, :114-121), the ids here
+stay in a per-page-table-row buffer that the worker gathers a decode batch's inputs
+from: the same hand-over, keyed by the row instead of by a ring position.  The other
+form (``overlap_worker=False``, and always on the CPU, where the reference's worker
+refuses to run, overlap_worker.py:50-53) does the same on ONE thread and ONE stream:
+every host-to-device copy of batch metadata goes through
 pinned staging memory without blocking, and the only wait of a step is on the event
 behind the PREVIOUS step's device-to-host copy of its ids.  As in the reference, a
 request that stops on its eos token is found out a step late, so it runs one decode step
@@ -43,6 +53,8 @@ next call, and a request is sampled from the call that holds its last prompt tok
 from __future__ import annotations
 
 import os
+import queue
+import threading
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple
 
@@ -98,9 +110,68 @@ def chunk_members(n_new: Sequence[int], limit: int):
         yield members
 
 
+class _ForwardWorker:
+    """The model's forward pass and the sampling on a thread and a HIP stream of their own
+    (reference: overlap_worker.py:27-160).  ``submit`` hands over a built batch and returns at
+    once; ``resolve`` gives the oldest submitted batch's ids on the host, waiting only for the
+    event behind their device-to-host copy.  A failure inside the worker is re-raised by
+    ``resolve``."""
+
+    def __init__(self, loop: "ServingLoop"):
+        self.loop = loop
+        self.stream = torch.cuda.Stream(device=loop.device)
+        self.inbox: "queue.Queue" = queue.Queue()
+        self.outbox: "queue.Queue" = queue.Queue()
+        self.thread = threading.Thread(target=self._main, name="bsgl-forward-worker", daemon=True)
+        self.thread.start()
+
+    def submit(self, mode: str, fb: SimplifiedForwardBatch, batch, logits_rows, ids_host) -> None:
+        # everything the batch needs was enqueued on the caller's stream: the forward stream waits for
+        # it on the device (the reference waits on the host instead, overlap_worker.py:83)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.loop.device))
+        self.inbox.put((mode, fb, batch, logits_rows, ids_host, ready))
+
+    def resolve(self):
+        item = self.outbox.get()
+        if isinstance(item, BaseException):
+            raise item
+        done, ids_host = item
+        done.synchronize()
+        return ids_host
+
+    def close(self) -> None:
+        self.inbox.put(None)
+        self.thread.join(timeout=30)
+        self.stream.synchronize()
+
+    def _main(self) -> None:
+        loop = self.loop
+        torch.cuda.set_device(loop.device)
+        with torch.cuda.stream(self.stream), torch.no_grad():
+            while True:
+                work = self.inbox.get()
+                if work is None:
+                    return
+                try:
+                    mode, fb, batch, logits_rows, ids_host, ready = work
+                    self.stream.wait_event(ready)
+                    if mode == "decode":
+                        # the ids the requests' last steps left on the device (overlap_worker.py:114-121)
+                        fb.input_ids = loop._last_ids[fb.req_pool_indices]
+                    next_ids = loop._pick(loop._model_logits(fb, logits_rows), batch)
+                    loop._last_ids[fb.req_pool_indices] = next_ids
+                    ids_host.copy_(next_ids, non_blocking=True)
+                    done = torch.cuda.Event()
+                    done.record(self.stream)
+                    self.outbox.put((done, ids_host))
+                except BaseException as exc:  # noqa: BLE001  (handed to the loop's thread by resolve)
+                    self.outbox.put(exc)
+
+
 class ServingLoop:
     def __init__(self, model, max_total_tokens: Optional[int] = None, max_requests: Optional[int] = None,
-                 chunked_prefill_size: Optional[int] = None):
+                 chunked_prefill_size: Optional[int] = None, overlap_worker: Optional[bool] = None):
         self.model = model
         if chunked_prefill_size is not None and chunked_prefill_size < 1:
             raise ValueError("chunked_prefill_size must be positive")
@@ -135,6 +206,11 @@ class ServingLoop:
         self._sampling = SamplingParams()
         self.generator: Optional[torch.Generator] = None  # for do_sample; None = the device's default generator
         self._ids_host = None  # pinned landing buffers of the per-step id copies, in the same rotation
+        # overlap mode: the model on a worker thread and a second stream (None: wherever there is a GPU)
+        self.overlap_worker = (self.device.type == "cuda") if overlap_worker is None else bool(overlap_worker)
+        if self.overlap_worker and self.device.type != "cuda":
+            raise NotImplementedError("the forward worker needs a GPU stream of its own (as the reference's, overlap_worker.py:50-53)")
+        self._worker: Optional[_ForwardWorker] = None
 
     def reset(self) -> None:
         self.req_to_token_pool.clear()
@@ -213,6 +289,10 @@ class ServingLoop:
                             max_new_tokens=min(sampling.max_new_tokens, self.max_total_tokens), eos_id=sampling.eos_id)
             self.waiting.append(seq)
             order.append(seq)
+        if self.overlap_worker:
+            if self._worker is None:
+                self._worker = _ForwardWorker(self)
+            return self._run_overlap_worker(order)
         pending = None  # (batch, mode, ids on the host, copy-done event, new slots on the host)
         while len(self.finished) < len(order) or pending is not None:
             batch, mode = self._select_overlap(pending is not None)
@@ -251,6 +331,59 @@ class ServingLoop:
                 self._commit_overlap(*pending)
             pending = submitted
         return [s.output_ids for s in order]
+
+    def _run_overlap_worker(self, order: List[Sequence_]) -> List[List[int]]:
+        """The overlap loop with the forward pass on the worker's thread and stream
+        (scheduler.py:647-698): build and submit batch t + 1, then take in batch t's ids."""
+        worker = self._worker
+        if self._ids_host is None:
+            self._ids_host = [torch.empty(self.max_requests, dtype=torch.long).pin_memory() for _ in range(3)]
+        pending = None  # (batch, mode, new slots on the host)
+        try:
+            while len(self.finished) < len(order) or pending is not None:
+                batch, mode = self._select_overlap(pending is not None)
+                if mode == "error" and pending is None:
+                    raise RuntimeError("Insufficient memory to process any requests")
+                submitted = None
+                if batch:
+                    self._next_staging()
+                    rows_for_logits = None
+                    if mode == "prefill":
+                        fb = self._prefill_batch(batch)
+                        n_new = [len(s.input_ids) - s.num_cached for s in batch]
+                        rows_for_logits = self._h2d(torch.cumsum(torch.tensor(n_new), dim=0) - 1, torch.long)
+                        host_loc = None
+                        for s in batch:  # decodable from the next step on (scheduler.py:676-681)
+                            self.waiting.remove(s)
+                            self.decoding.append(s)
+                    else:
+                        fb = self._decode_batch(batch, ids_on_device=True, gather_ids=False)
+                        host_loc = [s.table[s.seq_len - 1] for s in batch]
+                    if self.on_batch is not None:
+                        self.on_batch(mode, fb)
+                    for s in batch:
+                        s.in_flight += 1
+                    worker.submit(mode, fb, batch, rows_for_logits, self._ids_host[self._staging_turn][: len(batch)])
+                    submitted = (batch, mode, host_loc)
+                if pending is not None:
+                    p_batch, p_mode, p_loc = pending
+                    self._commit_overlap(p_batch, p_mode, worker.resolve(), None, p_loc)
+                pending = submitted
+        except BaseException:
+            # leave no batch behind on the worker: the next run starts from an empty queue
+            if pending is not None:
+                try:
+                    worker.resolve()
+                except BaseException:  # noqa: BLE001
+                    pass
+            raise
+        return [s.output_ids for s in order]
+
+    def close(self) -> None:
+        """End the forward worker's thread (a loop that never ran in overlap mode has none)."""
+        if self._worker is not None:
+            self._worker.close()
+            self._worker = None
 
     def _select_overlap(self, step_in_flight: bool) -> Tuple[List[Sequence_], str]:
         """``_select`` for a loop that has not seen the last step's ids yet: requests that have
@@ -317,6 +450,9 @@ class ServingLoop:
         ``logits_rows`` then skips the vocabulary projection of every other token)."""
         if self.on_batch is not None:
             self.on_batch(mode, fb)
+        return self._model_logits(fb, rows)
+
+    def _model_logits(self, fb: SimplifiedForwardBatch, rows: Optional[torch.Tensor] = None) -> torch.Tensor:
         with torch.no_grad():
             if rows is not None and getattr(self.model, "supports_logits_rows", False):
                 return self.model(fb.input_ids, fb.positions, fb, logits_rows=rows)
@@ -473,9 +609,11 @@ class ServingLoop:
             prefix_lens=self._h2d([s.num_cached for s in batch], torch.long),
         )
 
-    def _decode_batch(self, batch: List[Sequence_], ids_on_device: bool = False) -> SimplifiedForwardBatch:
+    def _decode_batch(self, batch: List[Sequence_], ids_on_device: bool = False, gather_ids: bool = True) -> SimplifiedForwardBatch:
         """One new token per request.  ``ids_on_device``: the tokens to feed are the ones the
-        requests' last steps left in the per-row id buffer (overlap mode), not ``output_ids[-1]``."""
+        requests' last steps left in the per-row id buffer (overlap mode), not ``output_ids[-1]``;
+        with ``gather_ids=False`` they are not gathered here (the forward worker does it on its own
+        stream, behind the step that produces them) and ``input_ids`` is a placeholder."""
         host_loc, new_slots = self._alloc_slots(len(batch))
         if host_loc is None:
             raise RuntimeError("Failed to allocate KV slots for decode")
@@ -488,7 +626,9 @@ class ServingLoop:
         seq_t = self._h2d([s.seq_len for s in batch], torch.long)
         # one indexed write appends every request's new slot to its page-table row
         self.req_to_token_pool.req_to_token[rows_t, seq_t - 1] = new_slots
-        if ids_on_device:
+        if ids_on_device and not gather_ids:
+            input_ids = torch.empty(len(batch), dtype=torch.long, device=self.device)
+        elif ids_on_device:
             input_ids = self._last_ids[rows_t]
         else:
             input_ids = self._h2d([s.output_ids[-1] for s in batch], torch.long)

@@ -93,15 +93,19 @@ def test_chunked_prefill_gives_the_reference_ids(gpu, limit):
     assert max(sizes) <= limit and len(sizes) > sum(1 for s in e2e["steps"] if s["mode"] == "prefill")
 
 
-def test_overlap_mode_on_the_gpu(gpu):
-    """Batches launched before the previous one's ids have been looked at (ids fed from the
-    device-side buffer, metadata through pinned staging): the reference's ids, also on a
-    second run that finds the prompts in the prefix tree, also with an eos that stops some
-    requests early (their extra step's slot is handed back)."""
+@pytest.mark.parametrize("worker", [True, False])
+def test_overlap_mode_on_the_gpu(gpu, worker):
+    """Batches launched before the previous one's ids have been looked at -- with the model on a
+    worker thread and a second stream (the reference's arrangement, overlap_worker.py:27-160) and
+    on one thread and one stream (ids fed from the device-side buffer, metadata through pinned
+    staging): the reference's ids, also on a second run that finds the prompts in the prefix tree,
+    also with an eos that stops some requests early (their extra step's slot is handed back)."""
     from baby_sglang_amd.serving_loop import SamplingParams, ServingLoop
 
     e2e = load_golden("driver_traces")["tiny_model_e2e"]
-    loop = ServingLoop(_tiny_model(gpu), max_total_tokens=e2e["max_total_tokens"], max_requests=e2e["max_requests"])
+    loop = ServingLoop(_tiny_model(gpu), max_total_tokens=e2e["max_total_tokens"], max_requests=e2e["max_requests"],
+                       overlap_worker=worker)
+    assert loop.overlap_worker is worker
     sp = SamplingParams(max_new_tokens=e2e["max_new_tokens"], eos_id=e2e["eos_id"])
     want = [o.tolist() for o in e2e["output_ids"]]
     assert [list(o) for o in loop.run_batch_overlap(e2e["prompts"], sp)] == want
@@ -115,3 +119,61 @@ def test_overlap_mode_on_the_gpu(gpu):
     assert a == b and len(a[0]) <= 3
     assert loop.req_to_token_pool.available_size() == e2e["max_requests"]
     assert loop.token_to_kv_pool.available_size() + loop.tree_cache.evictable_size() == e2e["max_total_tokens"]
+    loop.close()
+
+
+class _StandIn(torch.nn.Module):
+    """The stand-in model the reference scheduler's traces were made with (tests/test_serving_loop.py):
+    logits depend on (token id, position) only."""
+
+    def __init__(self, vocab):
+        super().__init__()
+        self.config = types.SimpleNamespace(num_key_value_heads=1, hidden_size=64, num_attention_heads=1,
+                                            num_hidden_layers=1, vocab_size=vocab)
+        self.dummy = torch.nn.Parameter(torch.zeros(1))
+
+    def forward(self, input_ids, positions, forward_batch, input_embeds=None):
+        v = self.config.vocab_size
+        return torch.nn.functional.one_hot((7 * input_ids + 3 * positions + 1) % v, v).float()
+
+
+@pytest.mark.parametrize("name", sorted(load_golden("driver_traces")["scenarios"]))
+def test_two_stream_overlap_gives_the_reference_schedulers_ids(gpu, name):
+    """The request streams of the reference scheduler's traces (shared prefixes, two admission
+    waves, eviction, eos stops) through the overlap loop with the forward pass on the worker's
+    thread and stream: the ids the reference's ``run_batch`` produced, twice on one loop (the second
+    run finds the prompts in the prefix tree), every row and slot handed back.  The ORDER of batches
+    in this mode is not pinned: the reference's worker refuses to run without CUDA
+    (overlap_worker.py:50-53), so no trace of it could be recorded."""
+    from baby_sglang_amd.serving_loop import SamplingParams, ServingLoop
+
+    traces = load_golden("driver_traces")
+    sc = traces["scenarios"][name]
+    model = _StandIn(traces["vocab"]).to(gpu)
+    loop = ServingLoop(model, max_total_tokens=sc["max_total_tokens"], max_requests=sc["max_requests"], overlap_worker=True)
+    sp = SamplingParams(max_new_tokens=sc["max_new_tokens"], eos_id=sc["eos_id"])
+    want = [o.tolist() for o in sc["output_ids"]]
+    threads = set()
+    loop.on_batch = lambda mode, fb: threads.add(torch.cuda.current_stream().cuda_stream)
+    for _ in range(2):
+        assert [list(o) for o in loop.run_batch_overlap(sc["prompts"], sp)] == want
+        assert loop.req_to_token_pool.available_size() == sc["max_requests"]
+        assert loop.token_to_kv_pool.available_size() + loop.tree_cache.evictable_size() == sc["max_total_tokens"]
+        assert all(s.in_flight == 0 for s in loop.finished)
+    assert loop._worker is not None and loop._worker.stream.cuda_stream not in threads  # batches are BUILT on the loop's stream
+    loop.close()
+
+
+def test_a_failure_inside_the_forward_worker_reaches_the_caller(gpu):
+    from baby_sglang_amd.serving_loop import SamplingParams, ServingLoop
+
+    class Broken(_StandIn):
+        def forward(self, input_ids, positions, forward_batch, input_embeds=None):
+            if not forward_batch.is_prefill:
+                raise ValueError("decode is broken in this model")
+            return super().forward(input_ids, positions, forward_batch)
+
+    loop = ServingLoop(Broken(31).to(gpu), max_total_tokens=256, max_requests=2, overlap_worker=True)
+    with pytest.raises(ValueError, match="decode is broken"):
+        loop.run_batch_overlap([torch.tensor([1, 2, 3]), torch.tensor([4, 5])], SamplingParams(max_new_tokens=4))
+    loop.close()
