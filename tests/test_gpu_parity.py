@@ -103,9 +103,12 @@ def test_golden_cases(gpu, name, layout, private_slots):
     want, k_want, v_want = oracle_exact(case)
     assert out.dtype == dtype and tuple(out.shape) == tuple(case["out"].shape)
     assert_close(out, want, dtype, f"{name} vs float64 oracle")
-    # and directly against what the reference produced (its own rounding included)
-    ref_tol = {torch.float32: 1e-5, torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dtype]
-    assert (out.double().cpu() - case["out"].double()).abs().max().item() <= ref_tol
+    # and directly against what the reference produced (its own rounding included): both sides are
+    # rounded to the dtype, so they may differ by ONE unit in the last place of a value of that size
+    # (observed on these cases, tools/golden_distance.py: bf16 7.8e-3 = 2^-7, f16 9.8e-4 = 2^-10, f32 9.5e-7)
+    ulp = {torch.float32: 2e-6, torch.float16: 2.0**-10, torch.bfloat16: 2.0**-7}[dtype]
+    ref = case["out"].double()
+    assert bool(((out.double().cpu() - ref).abs() <= ulp * ref.abs().clamp_min(1.0)).all())
     # KV write: bit exact, untouched slots untouched
     assert torch.equal(k_slab.cpu(), k_want) and torch.equal(v_slab.cpu(), v_want)
 
@@ -711,6 +714,8 @@ def test_extend_over_many_page_table_blocks(gpu, dtype, hq, hkv, dim):
     err = (got.double().cpu() - want).abs()
     bound = ulp * want.abs() + ulp * spread + 2e-4
     assert bool(torch.isfinite(got).all()) and bool((err <= bound).all()), f"worst excess {(err - bound).max().item():.3e}"
+    if dtype == torch.float16:
+        assert_close(got, want, dtype, "f16 extend against the stated bar (rtol 1e-3, atol 1e-3)")
 
 
 @pytest.mark.parametrize("dtype,hq,hkv,dim", [(torch.bfloat16, 28, 4, 128), (torch.float16, 12, 2, 128), (torch.bfloat16, 16, 2, 128),
@@ -738,6 +743,8 @@ def test_short_extends_share_one_stream(gpu, dtype, hq, hkv, dim):
     err = (got.double().cpu() - want).abs()
     bound = ulp * want.abs() + ulp * spread + 2e-4
     assert bool(torch.isfinite(got).all()) and bool((err <= bound).all()), f"worst excess {(err - bound).max().item():.3e}"
+    if dtype == torch.float16:
+        assert_close(got, want, dtype, "f16 extend against the stated bar (rtol 1e-3, atol 1e-3)")
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -770,6 +777,8 @@ def test_extend_scores_rising_along_the_sequence(gpu, dtype, slope):
     err = (got.double().cpu() - want).abs()
     bound = ulp * want.abs() + ulp * spread + 2e-4
     assert bool(torch.isfinite(got).all()) and bool((err <= bound).all()), f"worst excess {(err - bound).max().item():.3e}"
+    if dtype == torch.float16:
+        assert_close(got, want, dtype, "f16 extend against the stated bar (rtol 1e-3, atol 1e-3)")
 
 
 @pytest.mark.parametrize("seed", range(16))
