@@ -587,6 +587,8 @@ int bsgl_paged_prefill(void* out, int64_t out_row_stride, const void* q, int64_t
   {
     const int forced = bsgl::knob(bsgl::kKnobPrefillBlk);  // tuning override
     if (forced == 16 || forced == 64) pa.blk_rows = forced;
+    // (128: two four-wave teams share a K/V stream; only where the 32x32x16 kernel applies)
+    if (forced == 128 && n_kv_heads > 0 && n_q_heads / n_kv_heads >= 2) pa.blk_rows = 128;
   }
   ex.blk_rows = pa.blk_rows;
   // Groups of up to 8 consecutive blocks of a request share an XCD (and with it an L2).  The grid

@@ -29,7 +29,9 @@
 
 // Timing cuts of this translation unit (bit mask, tools/build_variant.sh sets it; RESULTS ARE WRONG
 // with any of them, they exist to price a phase): 4 = no K/V request inside the step loop, 8 = no
-// exponentials / multiply-adds / row sums / maxima, 64 = half of a step's K/V requests.
+// exponentials / multiply-adds / row sums / maxima, 64 = half of a step's K/V requests, 256 = every
+// request of the step loop re-reads the rows of the request's FIRST tokens (same instructions and LDS
+// writes, but served by the CU's own cache: what the traffic between L2 and the CU costs).
 #ifndef BSGL_CUT
 #define BSGL_CUT 0
 #endif
@@ -64,16 +66,20 @@ __device__ __forceinline__ constexpr int acc_row(int r, int hi) { return (r & 3)
 // PROF: the build with cycle stamps (per-phase sums into a.prof).  A build of its own: where a
 // stamped and an unstamped path join, the compiler waits for the stamp's value, and that wait
 // also waits for every LDS read on its way -- in the unstamped path too.
-template <typename Tag, int PW, bool PROF>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+// TEAMS: 1 = four waves, 64 positions x 2 q heads.  2 = eight waves, TWO such teams on consecutive
+// 64-position halves of a 128-position block that share one K/V stream (one workgroup per CU, two
+// waves per SIMD): half the K/V requests and half the bytes from L2 per product.
+template <typename Tag, int PW, bool PROF, int TEAMS = 1>
+__global__ __launch_bounds__(256 * TEAMS) __attribute__((amdgpu_waves_per_eu(2)))
 void prefill_mfma32_kernel(PrefillArgs a) {
   using E = Elem<Tag>;
+  static_assert(TEAMS == 1 || (TEAMS == 2 && PW == 32), "teams are halves of a 128-position block");
   constexpr int D = 128;
   constexpr int REC = 512;  // K row | V row of one kv head
-  constexpr int WAVES = 4;
+  constexpr int WAVES = 4 * TEAMS;
   constexpr int CH = 32 / PW;                    // q heads among a wave's columns
   constexpr int HPW = PW == 32 ? 2 : WAVES * CH;  // q heads per workgroup
-  constexpr int ROWS = PW == 32 ? 64 : PW;        // positions per workgroup
+  constexpr int ROWS = PW == 32 ? 64 * TEAMS : PW;  // positions per workgroup
   constexpr int NSTAGE = 4;
   constexpr int TILE_BYTES = kTile * REC;
   constexpr int STEP = 2 * kTile;                  // tokens per step: two tiles
@@ -85,7 +91,9 @@ void prefill_mfma32_kernel(PrefillArgs a) {
   constexpr int STAGE_OUT = 32 * kOPad * 4;        // output staging of one wave
   constexpr int BUF = RING > WAVES * STAGE_OUT ? RING : WAVES * STAGE_OUT;
   constexpr int SLOTS = kSlotBlock;
-  static_assert(SLOTS == 2 * 64 * WAVES && SLOTS / STEP == 16, "two entries per thread and block; steps per block as shifted below");
+  constexpr int NTHR = 64 * WAVES;
+  constexpr int EPT = SLOTS / NTHR;  // page-table entries of a block per thread: 2 (four waves) or 1 (eight)
+  static_assert(SLOTS == EPT * NTHR && SLOTS / STEP == 16, "whole entries per thread and block; steps per block as shifted below");
 
   __shared__ __attribute__((aligned(1024))) char smem[BUF + 2 * SLOTS * 4];
   int32_t* s_slots = (int32_t*)(smem + BUF);
@@ -138,12 +146,13 @@ void prefill_mfma32_kernel(PrefillArgs a) {
   if (two_blocks && (bi & 1)) return;
   const int q0_wg = (bg0 + nb - 1 - bi) * ROWS;
   const int rows_wg = (int)min((int64_t)ROWS, ext_raw - q0_wg);
-  const int hw = PW == 32 ? wave >> 1 : wave * CH;  // first of this wave's q heads among the workgroup's (or its block)
+  const int w4 = wave & 3, team = wave >> 2;       // (four waves: team 0)
+  const int hw = PW == 32 ? w4 >> 1 : wave * CH;  // first of this wave's q heads among the workgroup's (or its block)
   const int my_bi = bi + (two_blocks ? hw : 0);
   const bool head_ok = two_blocks ? my_bi < nb : hw < n_rt;  // no such head / block: the wave only helps to load
   const int q0_blk = (bg0 + nb - 1 - (head_ok ? my_bi : bi)) * ROWS;
   const int rows_blk = (int)min((int64_t)ROWS, ext_raw - q0_blk);
-  const int pos_off = PW == 32 ? 32 * (wave & 1) : 0;
+  const int pos_off = PW == 32 ? 32 * (w4 & 1) + 64 * team : 0;
   const int q0 = q0_blk + pos_off;
   const int n_heads = PW == 32 ? (head_ok ? 1 : 0) : max(0, min(CH, n_rt - hw));  // q heads this wave really has
   const int n_rows = n_heads > 0 ? max(0, min(PW, rows_blk - pos_off)) : 0;       // positions it really has
@@ -232,9 +241,11 @@ void prefill_mfma32_kernel(PrefillArgs a) {
   const uint64_t t_stage = PROF ? __builtin_readcyclecounter() : 0;
   if (PROF) prof[6] = (t_stage - t_entry) & 0xffffffffu;
   {
-    const uint32_t e0 = (uint32_t)*entry_ptr(tid), e1 = (uint32_t)*entry_ptr(tid + 256);
-    s_slots[tid] = entry_off(e0);
-    s_slots[tid + 256] = entry_off(e1);
+    uint32_t e[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) e[k] = (uint32_t)*entry_ptr(tid + k * NTHR);
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) s_slots[tid + k * NTHR] = entry_off(e[k]);
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);  // retire every compiler-visible load before the step loop
   __syncthreads();
@@ -260,16 +271,17 @@ void prefill_mfma32_kernel(PrefillArgs a) {
   // 78 cycles per request, this form 54).
   constexpr int NREQ = (BSGL_CUT & 64) ? DPW / 2 : DPW;
   uint64_t src4[DPW];
+  uint32_t off0[DPW] = {};  // (BSGL_CUT & 256: the offsets of step 0)
   auto make_src = [&]() {
 #pragma unroll
     for (int j = 0; j < DPW; ++j) {
       const int i = wave * DPW + j;  // wave-uniform: request i brings tokens 2i, 2i+1 of the step (tile i / 8)
       const uint32_t xr = (uint32_t)xr_of_rec(rec_of_token(2 * (i & 7)));
-      src4[j] = (((uint64_t)off[j] << 4) + lane_src) ^ (uint64_t)(xr << 4);
+      src4[j] = (((uint64_t)((BSGL_CUT & 256) ? off0[j] : off[j]) << 4) + lane_src) ^ (uint64_t)(xr << 4);
     }
   };
   auto issue_step = [&](int step) {
-    static_assert(DPW == 4, "one statement of four requests");
+    static_assert(NREQ == 4 || NREQ == 2, "one statement of four or two requests");
     const uint32_t stage = lds_ring + (uint32_t)(step % NSTAGE) * STEP_BYTES;
     uint32_t dst[DPW];
 #pragma unroll
@@ -278,7 +290,7 @@ void prefill_mfma32_kernel(PrefillArgs a) {
       dst[j] = __builtin_amdgcn_readfirstlane(stage + (uint32_t)(i >> 3) * TILE_BYTES + (uint32_t)rec_of_token(2 * (i & 7)) * REC);
     }
     uint32_t keep;
-    if constexpr (NREQ == DPW) {
+    if constexpr (NREQ == 4) {
       asm volatile(
           "s_mov_b32 %0, m0\n\t"
           "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
@@ -302,7 +314,15 @@ void prefill_mfma32_kernel(PrefillArgs a) {
   };
 
   if (PROF) prof[5] += (__builtin_readcyclecounter() - t_stage) << 32;
-  if (n_steps > 0) { read_offsets(0); make_src(); issue_step(0); }
+  if (n_steps > 0) {
+    read_offsets(0);
+    if constexpr ((BSGL_CUT & 256) != 0) {
+#pragma unroll
+      for (int j = 0; j < DPW; ++j) off0[j] = off[j];
+    }
+    make_src();
+    issue_step(0);
+  }
   if (n_steps > 1) { read_offsets(1); make_src(); issue_step(1); }
   if (n_steps > 2) { read_offsets(2); make_src(); issue_step(2); }
   if (n_steps > 3) read_offsets(3);
@@ -360,15 +380,17 @@ void prefill_mfma32_kernel(PrefillArgs a) {
         // this wave's share of step + 1 has landed (one younger step may stay in flight, and in
         // step 16 b + 3 the two entry loads behind it) ...
         if (step + 2 >= n_steps) dma_wait<0>();
-        else if (in_blk == 3 && more_entries) dma_wait<NREQ + 2>();
+        else if (in_blk == 3 && more_entries) dma_wait<NREQ + EPT>();
         else dma_wait<NREQ>();
         t1 = PROF ? __builtin_readcyclecounter() : 0;
         if (in_blk == 4 && more_entries) {
           // (this wave's own two pieces, landed by the wait above; the barrier below publishes them)
           int32_t* half = s_slots + (((step >> 4) + 1) & 1) * SLOTS;
-          const uint32_t e0 = (uint32_t)half[tid], e1 = (uint32_t)half[tid + 256];
-          half[tid] = entry_off(e0);
-          half[tid + 256] = entry_off(e1);
+          uint32_t e[EPT];
+#pragma unroll
+          for (int k = 0; k < EPT; ++k) e[k] = (uint32_t)half[tid + k * NTHR];
+#pragma unroll
+          for (int k = 0; k < EPT; ++k) half[tid + k * NTHR] = entry_off(e[k]);
         }
         // ... and so has everybody's; all waves are also done reading step - 1
         __syncthreads();
@@ -381,8 +403,9 @@ void prefill_mfma32_kernel(PrefillArgs a) {
         if (in_blk == 2 && more_entries) {
           const int e = ((step >> 4) + 1) * SLOTS + tid;
           const uint32_t half = lds_slots + (uint32_t)((((step >> 4) + 1) & 1) * SLOTS * 4) + (uint32_t)wave * 256u;
-          dma_256((const void*)entry_ptr(e), __builtin_amdgcn_readfirstlane(half));
-          dma_256((const void*)entry_ptr(e + 256), __builtin_amdgcn_readfirstlane(half + 1024u));
+#pragma unroll
+          for (int k = 0; k < EPT; ++k)
+            dma_256((const void*)entry_ptr(e + k * NTHR), __builtin_amdgcn_readfirstlane(half + (uint32_t)(k * NTHR * 4)));
         }
       }
       const uint64_t t3 = PROF ? __builtin_readcyclecounter() : 0;
@@ -539,22 +562,28 @@ void prefill_mfma32_kernel(PrefillArgs a) {
 }  // namespace
 
 bool prefill_mfma32_supported(const PrefillArgs& a) {
-  return (a.blk_rows == 64 || a.blk_rows == 16) && a.n_kv_heads > 0 && a.n_q_heads / a.n_kv_heads >= 2;
+  return (a.blk_rows == 128 || a.blk_rows == 64 || a.blk_rows == 16) && a.n_kv_heads > 0 && a.n_q_heads / a.n_kv_heads >= 2;
 }
 
 // the grid of paged_prefill_mfma.hip's launch with 2 (64-position blocks) or 8 (16-position
 // blocks) q heads per workgroup
 hipError_t launch_prefill_mfma32(const PrefillArgs& a, hipStream_t stream) {
   const int group = a.n_q_heads / a.n_kv_heads;
-  const int hpw = a.blk_rows == 64 ? 2 : 8;
+  const int hpw = a.blk_rows >= 64 ? 2 : 8;
   const int n_z = (group + hpw - 1) / hpw;
   const int64_t local_groups = ((int64_t)a.max_groups * a.n_kv_heads + 7) / 8;
   const int64_t n_wg = 8 * local_groups * a.grp_blocks * n_z;
   if (n_wg > 0x7fffffffll) return hipErrorInvalidValue;
   dim3 grid((unsigned)n_wg, 1, 1);
   const unsigned pad = (unsigned)max(0, knob(kKnobPrefillLdsPad));  // tuning aid: extra LDS per workgroup, to lower the occupancy
-  auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(256), pad, stream, a); };
+  auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, grid, dim3(a.blk_rows == 128 ? 512 : 256), pad, stream, a); };
   const bool prof = a.prof != nullptr;
+#ifndef BSGL_NO_TEAMS2
+  if (a.blk_rows == 128) {
+    if (a.dtype == kBF16) prof ? go(prefill_mfma32_kernel<bf16_tag, 32, true, 2>) : go(prefill_mfma32_kernel<bf16_tag, 32, false, 2>);
+    else prof ? go(prefill_mfma32_kernel<f16_tag, 32, true, 2>) : go(prefill_mfma32_kernel<f16_tag, 32, false, 2>);
+  } else
+#endif
   if (a.blk_rows == 64) {
     if (a.dtype == kBF16) prof ? go(prefill_mfma32_kernel<bf16_tag, 32, true>) : go(prefill_mfma32_kernel<bf16_tag, 32, false>);
     else prof ? go(prefill_mfma32_kernel<f16_tag, 32, true>) : go(prefill_mfma32_kernel<f16_tag, 32, false>);

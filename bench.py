@@ -251,10 +251,18 @@ class Workload:
         for layer in range(self.args.layers):
             fwd(self.q[layer], self.k[layer], self.v_rows(layer), self.layers[layer], self.fb)
 
-    def algorithmic_bytes_per_layer(self):
+    def algorithmic_bytes_per_layer(self, shared_rows_once=False):
+        """Bytes one layer call has to move: the K and V rows of every visible token, the page-table
+        entries, q, out and the new rows.  ``shared_rows_once``: a cache row that several requests'
+        page tables name (a shared prefix) is counted once, not once per request."""
         B, D, eb = self.args.batch, self.dim, 2
         tokens = int(self.local_seq.sum().item())
-        kv = 2 * tokens * self.hkv_l * D * eb
+        kv_rows = tokens
+        if shared_rows_once:
+            table = self.r2t.req_to_token[self.req]
+            visible = torch.arange(table.shape[1], device=table.device)[None, :] < self.local_seq[:, None]
+            kv_rows = int(torch.unique(table[visible]).numel())
+        kv = 2 * kv_rows * self.hkv_l * D * eb
         table = tokens * 4
         q = B * self.hq_l * D * eb
         out = B * self.hq_l * D * (4 if self.out_f32 else eb)
@@ -742,6 +750,14 @@ def main():
             ms = timed_steps(r3, args.steps, args.warmup, 1) / args.steps * 1e3
             extras[f"{alt}_table_ms_per_step"] = ms
             extras[f"{alt}_table_tokens_per_s"] = args.batch / ms * 1e3
+            # the same roofline arithmetic as the headline's, on this table's own bytes (whole step / 28
+            # launches, launch boundaries included); the radix table counts a shared cache row once
+            alt_b, _ = wl.algorithmic_bytes_per_layer(shared_rows_once=alt == "radix")
+            extras[f"{alt}_table_algorithmic_bytes_per_launch"] = alt_b
+            extras[f"{alt}_table_frac_of_hbm_peak"] = alt_b * args.layers / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            if alt == "radix":
+                extras["radix_table_note"] = ("groups of 8 requests share the cache rows of their first half: shared rows counted "
+                                              "once in the bytes (they are read from HBM once and served from cache after that)")
             if alt == "ragged":
                 extras["ragged_mean_seq"] = float(wl.local_seq.float().mean().item())
         wl.set_table(args.table)
