@@ -31,9 +31,14 @@
 // with any of them, they exist to price a phase): 4 = no K/V request inside the step loop, 8 = no
 // exponentials / multiply-adds / row sums / maxima, 64 = half of a step's K/V requests, 256 = every
 // request of the step loop re-reads the rows of the request's FIRST tokens (same instructions and LDS
-// writes, but served by the CU's own cache: what the traffic between L2 and the CU costs).
+// writes, but served by the CU's own cache: what the traffic between L2 and the CU costs), 512 = the
+// whole K/V stream of the workgroup is run through TWICE (one prologue, one epilogue: the difference
+// to the plain launch is what a pass over the stream costs without them).
 #ifndef BSGL_CUT
 #define BSGL_CUT 0
+#endif
+#ifndef BSGL_T2_MODE
+#define BSGL_T2_MODE 1
 #endif
 
 namespace bsgl {
@@ -80,7 +85,17 @@ void prefill_mfma32_kernel(PrefillArgs a) {
   constexpr int CH = 32 / PW;                    // q heads among a wave's columns
   constexpr int HPW = PW == 32 ? 2 : WAVES * CH;  // q heads per workgroup
   constexpr int ROWS = PW == 32 ? 64 * TEAMS : PW;  // positions per workgroup
-  constexpr int NSTAGE = 4;
+  // SUB steps of 32 tokens form a group: the unit of the K/V requests, of the wait for them and of the
+  // workgroup barrier.  Four waves: 1 (two workgroups per CU share the LDS).  Eight waves: 2 -- both
+  // waves of a SIMD then sit behind the same barrier, so the time around a barrier is time the matrix
+  // pipe idles, and the workgroup has the CU's LDS to itself for a ring twice as deep.
+  // Eight waves, BSGL_T2_MODE (build switch, default 2): bit 0 = SUB 2, bit 1 = the second team runs
+  // half a step behind the first (STAGGER): its wait / barrier / requests of step s + 1 sit between the
+  // score half and the PV half of its step s, so that on every SIMD one wave is in its score half
+  // (exponentials, K reads) while the other is in its PV half, instead of both in the same half.
+  constexpr int SUB = (TEAMS == 2 && (BSGL_T2_MODE & 1)) ? 2 : 1;
+  constexpr bool STAGGER = TEAMS == 2 && (BSGL_T2_MODE & 2) != 0 && SUB == 1;
+  constexpr int NSTAGE = TEAMS == 2 ? 8 : 4;
   constexpr int TILE_BYTES = kTile * REC;
   constexpr int STEP = 2 * kTile;                  // tokens per step: two tiles
   constexpr int STEP_BYTES = 2 * TILE_BYTES;
@@ -259,35 +274,39 @@ void prefill_mfma32_kernel(PrefillArgs a) {
   // instruction i brings tokens 2i, 2i+1 of the step (tile i / 8)
   // (the row offsets of a step are read from s_slots one request early, so that the request
   // itself does not start with an LDS round trip)
-  uint32_t off[DPW];
-  auto read_offsets = [&](int step) {
-    const int32_t* ent = s_slots + ((step * STEP) & (2 * SLOTS - 1)) + 2 * wave * DPW + lane_tok;
+  // a group's requests of this wave: request r (0 .. NREQ_ALL-1) belongs to step g * SUB + r / DPW of
+  // group g and is instruction wave * DPW + r % DPW of that step
+  constexpr int NREQ_ALL = SUB * DPW;
+  static_assert(NREQ_ALL == 4 || NREQ_ALL == 2, "four or two requests per wave and group");
+  uint32_t off[NREQ_ALL];
+  auto read_offsets = [&](int group) {
 #pragma unroll
-    for (int j = 0; j < DPW; ++j) off[j] = (uint32_t)ent[2 * j];
-  };
-  // A step's requests of this wave: the four source addresses are made ahead of the wait and the
-  // barrier of the step that issues them (make_src), and the requests then go out as ONE statement,
-  // M0 set per request and restored once (four statements with their address arithmetic in between:
-  // 78 cycles per request, this form 54).
-  constexpr int NREQ = (BSGL_CUT & 64) ? DPW / 2 : DPW;
-  uint64_t src4[DPW];
-  uint32_t off0[DPW] = {};  // (BSGL_CUT & 256: the offsets of step 0)
-  auto make_src = [&]() {
-#pragma unroll
-    for (int j = 0; j < DPW; ++j) {
-      const int i = wave * DPW + j;  // wave-uniform: request i brings tokens 2i, 2i+1 of the step (tile i / 8)
-      const uint32_t xr = (uint32_t)xr_of_rec(rec_of_token(2 * (i & 7)));
-      src4[j] = (((uint64_t)((BSGL_CUT & 256) ? off0[j] : off[j]) << 4) + lane_src) ^ (uint64_t)(xr << 4);
+    for (int r = 0; r < NREQ_ALL; ++r) {
+      const int step = group * SUB + r / DPW;
+      off[r] = (uint32_t)s_slots[((step * STEP) & (2 * SLOTS - 1)) + 2 * (wave * DPW + r % DPW) + lane_tok];
     }
   };
-  auto issue_step = [&](int step) {
-    static_assert(NREQ == 4 || NREQ == 2, "one statement of four or two requests");
-    const uint32_t stage = lds_ring + (uint32_t)(step % NSTAGE) * STEP_BYTES;
-    uint32_t dst[DPW];
+  // The four source addresses are made ahead of the wait and the barrier of the step that issues them
+  // (make_src), and the requests then go out as ONE statement, M0 set per request and restored once
+  // (four statements with their address arithmetic in between: 78 cycles per request, this form 54).
+  constexpr int NREQ = (BSGL_CUT & 64) && NREQ_ALL == 4 ? NREQ_ALL / 2 : NREQ_ALL;
+  uint64_t src4[NREQ_ALL];
+  uint32_t off0[NREQ_ALL] = {};  // (BSGL_CUT & 256: the offsets of group 0)
+  auto make_src = [&]() {
 #pragma unroll
-    for (int j = 0; j < DPW; ++j) {
-      const int i = wave * DPW + j;
-      dst[j] = __builtin_amdgcn_readfirstlane(stage + (uint32_t)(i >> 3) * TILE_BYTES + (uint32_t)rec_of_token(2 * (i & 7)) * REC);
+    for (int r = 0; r < NREQ_ALL; ++r) {
+      const int i = wave * DPW + r % DPW;  // wave-uniform: instruction i brings tokens 2i, 2i+1 of its step (tile i / 8)
+      const uint32_t xr = (uint32_t)xr_of_rec(rec_of_token(2 * (i & 7)));
+      src4[r] = (((uint64_t)((BSGL_CUT & 256) ? off0[r] : off[r]) << 4) + lane_src) ^ (uint64_t)(xr << 4);
+    }
+  };
+  auto issue_group = [&](int group) {
+    uint32_t dst[NREQ_ALL];
+#pragma unroll
+    for (int r = 0; r < NREQ_ALL; ++r) {
+      const int i = wave * DPW + r % DPW;
+      const uint32_t stage = lds_ring + (uint32_t)((group * SUB + r / DPW) % NSTAGE) * STEP_BYTES;
+      dst[r] = __builtin_amdgcn_readfirstlane(stage + (uint32_t)(i >> 3) * TILE_BYTES + (uint32_t)rec_of_token(2 * (i & 7)) * REC);
     }
     uint32_t keep;
     if constexpr (NREQ == 4) {
@@ -314,25 +333,28 @@ void prefill_mfma32_kernel(PrefillArgs a) {
   };
 
   if (PROF) prof[5] += (__builtin_readcyclecounter() - t_stage) << 32;
-  if (n_steps > 0) {
+  const int n_groups = (n_steps + SUB - 1) / SUB;
+  f32x16 sc_a, sc_b;
+  float lmax_nx = kNegInf;
+  for (int pass = 0; pass < ((BSGL_CUT & 512) ? 2 : 1); ++pass) {
+  if (pass > 0) __syncthreads();
+  if (n_groups > 0) {
     read_offsets(0);
     if constexpr ((BSGL_CUT & 256) != 0) {
 #pragma unroll
-      for (int j = 0; j < DPW; ++j) off0[j] = off[j];
+      for (int r = 0; r < NREQ_ALL; ++r) off0[r] = off[r];
     }
     make_src();
-    issue_step(0);
+    issue_group(0);
   }
-  if (n_steps > 1) { read_offsets(1); make_src(); issue_step(1); }
-  if (n_steps > 2) { read_offsets(2); make_src(); issue_step(2); }
-  if (n_steps > 3) read_offsets(3);
+  if (n_groups > 1) { read_offsets(1); make_src(); issue_group(1); }
+  if (n_groups > 2) { read_offsets(2); make_src(); issue_group(2); }
+  if (n_groups > 3) read_offsets(3);
 
-  // raw scores of the step about to be consumed and of the one after it: the two trade places
-  // from step to step (a copy would wait for the last score product)
-  f32x16 sc_a, sc_b;
-  // largest of the lane's 16 raw scores of the step that comes next, found in the shadow of that
+  // sc_a, sc_b: raw scores of the step about to be consumed and of the one after it: the two trade
+  // places from step to step (a copy would wait for the last score product)
+  // lmax_nx: largest of the lane's 16 raw scores of the step that comes next, found in the shadow of that
   // step's predecessor's PV products (steps that need the mask look again, after masking)
-  float lmax_nx = kNegInf;
   auto max16 = [&](const f32x16& v) {
     float m = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
     return fmaxf(m, fmaxf(fmaxf(fmaxf(v[8], v[9]), fmaxf(v[10], v[11])), fmaxf(fmaxf(v[12], v[13]), fmaxf(v[14], v[15]))));
@@ -350,7 +372,7 @@ void prefill_mfma32_kernel(PrefillArgs a) {
     return s;
   };
   {
-    if (n_steps > 2) dma_wait<2 * DPW>(); else if (n_steps > 1) dma_wait<DPW>(); else dma_wait<0>();
+    if (n_groups > 2) dma_wait<2 * NREQ>(); else if (n_groups > 1) dma_wait<NREQ>(); else dma_wait<0>();
     __syncthreads();
     if (0 < wave_len) {
       uint4 kf[8];
@@ -362,29 +384,31 @@ void prefill_mfma32_kernel(PrefillArgs a) {
 
   {
     constexpr int blk = 0;
-    auto do_step = [&](int step, auto stage_c, f32x16& sc, f32x16& sn) {
-      constexpr int STAGE = decltype(stage_c)::value;
-      constexpr int NEXT = (STAGE + 1) % NSTAGE;
+    // the head of a step: wait for this wave's share of the next group, the workgroup barrier, the
+    // requests of the group three ahead
+    auto top = [&](int step) {
       const uint64_t t0 = PROF ? __builtin_readcyclecounter() : 0;
-      const bool has_next = step + 1 < n_steps;  // wave-uniform
       uint64_t t1 = t0, t2 = t0;
-      // the entries of block b + 1 are asked for in step 16 b + 2 (behind that step's K/V
-      // requests), have arrived by the wait of step 16 b + 4 and are stored then; their half of
-      // s_slots was last read for step 16 b - 1, requested in step 16 b - 4, and is first read
-      // for step 16 b + 16, requested in step 16 b + 13
+      // the entries of block b + 1 are asked for at the head of step 16 b + 2 (behind that group's K/V
+      // requests), have arrived by the wait one group after the next and are turned into row offsets
+      // there; their half of s_slots was last read for step 16 b - 1 and is first read for step
+      // 16 b + 16, whose requests go out three groups ahead of it
       const int in_blk = step & (SLOTS / STEP - 1);
+      const int group = step / SUB;                    // (SUB is 1 or 2)
+      const bool head = step % SUB == 0;               // the group's first step: wait, barrier, requests
       const bool more_entries = ((step >> 4) + 1) * SLOTS < kv_len;  // wave-uniform
-      const bool issue_ok = ((BSGL_CUT & 4) == 0) && has_next && step + 3 < n_steps;  // wave-uniform
-      if (issue_ok) make_src();  // the addresses of this step's requests, ahead of the wait
+      const bool has_next = head && group + 1 < n_groups;           // wave-uniform
+      const bool issue_ok = ((BSGL_CUT & 4) == 0) && has_next && group + 3 < n_groups;  // wave-uniform
+      if (issue_ok) make_src();  // the addresses of this group's requests, ahead of the wait
       if (has_next) {
-        // this wave's share of step + 1 has landed (one younger step may stay in flight, and in
-        // step 16 b + 3 the two entry loads behind it) ...
-        if (step + 2 >= n_steps) dma_wait<0>();
-        else if (in_blk == 3 && more_entries) dma_wait<NREQ + EPT>();
+        // this wave's share of the next group has landed (one younger group may stay in flight, and
+        // one group after the entries were asked for, those behind it) ...
+        if (group + 2 >= n_groups) dma_wait<0>();
+        else if (in_blk == 2 + SUB && more_entries) dma_wait<NREQ + EPT>();
         else dma_wait<NREQ>();
         t1 = PROF ? __builtin_readcyclecounter() : 0;
-        if (in_blk == 4 && more_entries) {
-          // (this wave's own two pieces, landed by the wait above; the barrier below publishes them)
+        if (in_blk == 2 + 2 * SUB && more_entries) {
+          // (this wave's own pieces, landed by the wait above; the barrier below publishes them)
           int32_t* half = s_slots + (((step >> 4) + 1) & 1) * SLOTS;
           uint32_t e[EPT];
 #pragma unroll
@@ -392,14 +416,13 @@ void prefill_mfma32_kernel(PrefillArgs a) {
 #pragma unroll
           for (int k = 0; k < EPT; ++k) half[tid + k * NTHR] = entry_off(e[k]);
         }
-        // ... and so has everybody's; all waves are also done reading step - 1
+        // ... and so has everybody's; all waves are also done reading the group before this one
         __syncthreads();
         t2 = PROF ? __builtin_readcyclecounter() : 0;
-        // the row offsets of step + 4 are asked for first (any entries if there is no such step: they
-        // are then never used) and travel while this step's requests go out (read behind the requests,
-        // the wave waited for them before it could ask for its K fragments: 100 cycles per step)
-        read_offsets(step + 4);
-        if (issue_ok) issue_step(step + 3);  // into the stage step - 1 used
+        // the row offsets of the group after the one requested now are asked for first (any entries if
+        // there is no such group: they are then never used) and travel while the requests go out
+        read_offsets(group + 4);
+        if (issue_ok) issue_group(group + 3);  // into the stages the group before this one used
         if (in_blk == 2 && more_entries) {
           const int e = ((step >> 4) + 1) * SLOTS + tid;
           const uint32_t half = lds_slots + (uint32_t)((((step >> 4) + 1) & 1) * SLOTS * 4) + (uint32_t)wave * 256u;
@@ -410,8 +433,19 @@ void prefill_mfma32_kernel(PrefillArgs a) {
       }
       const uint64_t t3 = PROF ? __builtin_readcyclecounter() : 0;
       if (PROF) { prof[0] += t1 - t0; prof[1] += t2 - t1; prof[2] += t3 - t2; prof[5] += 1; }
+    };
+    const bool late_team = STAGGER && team == 1;  // wave-uniform
+    auto do_step = [&](int step, auto stage_c, f32x16& sc, f32x16& sn) {
+      constexpr int STAGE = decltype(stage_c)::value;
+      constexpr int NEXT = (STAGE + 1) % NSTAGE;
+      // (the late team has run this step's head already, between the halves of the step before)
+      if (!late_team || step == 0) top(step);
+      const uint64_t t3 = PROF ? __builtin_readcyclecounter() : 0;
       const char* st = smem + STAGE * STEP_BYTES;
-      if (blk + step * STEP >= wave_len) return;  // nothing this wave's rows may see (wave-uniform)
+      if (blk + step * STEP >= wave_len) {  // nothing this wave's rows may see (wave-uniform)
+        if (late_team && step + 1 < n_steps) top(step + 1);
+        return;
+      }
 
       // K fragments of step + 1 (whatever the stage holds if there is no such step: the scores
       // made of them are then never used); they travel while the maximum is looked at
@@ -487,6 +521,10 @@ void prefill_mfma32_kernel(PrefillArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       }
       if (PROF) prof[4] += __builtin_readcyclecounter() - t3;  // the score half of the body
+      if constexpr (STAGGER) {
+        if (late_team && step + 1 < n_steps) top(step + 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       // k-values of a lane in PV product i: registers 8 kk .. 8 kk + 7 of the score accumulator,
       // i.e. tokens {0-3, 8-11} + 4 hi of tile kk = i >> 2
 #pragma unroll
@@ -510,15 +548,22 @@ void prefill_mfma32_kernel(PrefillArgs a) {
       }
       if (PROF) prof[3] += __builtin_readcyclecounter() - t3;
     };
-    static_assert(NSTAGE == 4, "the step loop below is unrolled over the ring");
-    for (int step = 0; step < n_steps; step += 4) {
+    static_assert(NSTAGE == 4 || NSTAGE == 8, "the step loop below is unrolled over the ring");
+    for (int step = 0; step < n_steps; step += NSTAGE) {
       do_step(step, std::integral_constant<int, 0>{}, sc_a, sc_b);
       if (step + 1 < n_steps) do_step(step + 1, std::integral_constant<int, 1>{}, sc_b, sc_a);
       if (step + 2 < n_steps) do_step(step + 2, std::integral_constant<int, 2>{}, sc_a, sc_b);
       if (step + 3 < n_steps) do_step(step + 3, std::integral_constant<int, 3>{}, sc_b, sc_a);
+      if constexpr (NSTAGE == 8) {
+        if (step + 4 < n_steps) do_step(step + 4, std::integral_constant<int, 4>{}, sc_a, sc_b);
+        if (step + 5 < n_steps) do_step(step + 5, std::integral_constant<int, 5>{}, sc_b, sc_a);
+        if (step + 6 < n_steps) do_step(step + 6, std::integral_constant<int, 6>{}, sc_a, sc_b);
+        if (step + 7 < n_steps) do_step(step + 7, std::integral_constant<int, 7>{}, sc_b, sc_a);
+      }
     }
   }
 
+  }  // (pass)
   const uint64_t t_loop_end = PROF ? __builtin_readcyclecounter() : 0;
   // ---- normalise and write: rows through LDS so that a lane stores 16 contiguous bytes ----
   __syncthreads();  // the ring is free: each wave stages its rows in its own region
