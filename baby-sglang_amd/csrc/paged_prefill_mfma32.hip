@@ -29,8 +29,8 @@
 
 // Timing cuts of this translation unit (bit mask, tools/build_variant.sh sets it; RESULTS ARE WRONG
 // with any of them, they exist to price a phase): 4 = no K/V request inside the step loop, 8 = no
-// exponentials / multiply-adds / row sums / maxima, 16 = no LDS read of K / V fragments in the loop, 32 = (opposite-phase
-// form) no compute phase, 64 = half of a step's K/V requests, 256 = every
+// exponentials / multiply-adds / row sums / maxima, 16 = no LDS read of K / V fragments in the loop,
+// 64 = half of a step's K/V requests, 256 = every
 // request of the step loop re-reads the rows of the request's FIRST tokens (same instructions and LDS
 // writes, but served by the CU's own cache: what the traffic between L2 and the CU costs), 512 = the
 // whole K/V stream of the workgroup is run through TWICE (one prologue, one epilogue: the difference
@@ -90,27 +90,12 @@ void prefill_mfma32_kernel(PrefillArgs a) {
   // workgroup barrier.  Four waves: 1 (two workgroups per CU share the LDS).  Eight waves: 2 -- both
   // waves of a SIMD then sit behind the same barrier, so the time around a barrier is time the matrix
   // pipe idles, and the workgroup has the CU's LDS to itself for a ring twice as deep.
-  // Eight waves, BSGL_T2_MODE (build switch, default 2): bit 0 = SUB 2, bit 1 = the second team runs
+  // Eight waves, BSGL_T2_MODE (build switch, default 1): bit 0 = SUB 2, bit 1 = the second team runs
   // half a step behind the first (STAGGER): its wait / barrier / requests of step s + 1 sit between the
   // score half and the PV half of its step s, so that on every SIMD one wave is in its score half
   // (exponentials, K reads) while the other is in its PV half, instead of both in the same half.
-  // bit 2 = the two teams in opposite PHASES (PP): a step is a load phase (the step's V fragments and the
-  // next step's K fragments from LDS into registers, the wait for the wave's own requests, new requests)
-  // and a compute phase (16 products with the softmax arithmetic in their gaps, no LDS read), each closed
-  // by a workgroup barrier; the second team runs one phase behind the first, so every SIMD always holds one
-  // wave in its compute phase and one in its load phase.
-  constexpr bool PP = TEAMS == 2 && (BSGL_T2_MODE & 4) != 0;
-  // bit 3 (with bit 2): the softmax arithmetic moves into the load phase as well, so that the compute phase
-  // is the 16 products back to back and nothing else -- the wave that computes needs the matrix pipe only,
-  // its partner the vector, LDS and memory pipes only.
-  constexpr bool PPMS = PP && (BSGL_T2_MODE & 8) != 0;
-  // bit 4: the V fragments are read at the head of the compute phase (they are first used half a phase
-  // later) instead of in the load phase; bit 5: the compute phase runs at a raised issue priority.
-  constexpr bool PP_VLATE = PP && !PPMS && (BSGL_T2_MODE & 16) != 0;
-  constexpr bool PP_PRIO = PP && (BSGL_T2_MODE & 32) != 0;
-  constexpr int SUB = (TEAMS == 2 && (BSGL_T2_MODE & 1) && !PP) ? 2 : 1;
-  constexpr bool STAGGER = TEAMS == 2 && (BSGL_T2_MODE & 2) != 0 && SUB == 1 && !PP;
-  constexpr int AH = 6;  // PP: a step's K/V requests go out this many steps ahead of its first read
+  constexpr int SUB = (TEAMS == 2 && (BSGL_T2_MODE & 1)) ? 2 : 1;
+  constexpr bool STAGGER = TEAMS == 2 && (BSGL_T2_MODE & 2) != 0 && SUB == 1;
   constexpr int NSTAGE = TEAMS == 2 ? 8 : 4;
   constexpr int TILE_BYTES = kTile * REC;
   constexpr int STEP = 2 * kTile;                  // tokens per step: two tiles
@@ -354,12 +339,6 @@ void prefill_mfma32_kernel(PrefillArgs a) {
   float lmax_nx = kNegInf;
   for (int pass = 0; pass < ((BSGL_CUT & 512) ? 2 : 1); ++pass) {
   if (pass > 0) __syncthreads();
-  if constexpr (PP) {
-#pragma unroll
-    for (int y = 0; y < AH; ++y)
-      if (y < n_steps) { read_offsets(y); make_src(); issue_group(y); }
-    read_offsets(AH);
-  } else {
   if (n_groups > 0) {
     read_offsets(0);
     if constexpr ((BSGL_CUT & 256) != 0) {
@@ -372,7 +351,6 @@ void prefill_mfma32_kernel(PrefillArgs a) {
   if (n_groups > 1) { read_offsets(1); make_src(); issue_group(1); }
   if (n_groups > 2) { read_offsets(2); make_src(); issue_group(2); }
   if (n_groups > 3) read_offsets(3);
-  }
 
   // sc_a, sc_b: raw scores of the step about to be consumed and of the one after it: the two trade
   // places from step to step (a copy would wait for the last score product)
@@ -395,12 +373,7 @@ void prefill_mfma32_kernel(PrefillArgs a) {
     return s;
   };
   {
-    if constexpr (PP) {
-      // (steps 0 and 1 are read before the first wait of the loop)
-      if (n_steps >= AH) dma_wait<NREQ * (AH - 2)>(); else dma_wait<0>();
-    } else {
-      if (n_groups > 2) dma_wait<2 * NREQ>(); else if (n_groups > 1) dma_wait<NREQ>(); else dma_wait<0>();
-    }
+    if (n_groups > 2) dma_wait<2 * NREQ>(); else if (n_groups > 1) dma_wait<NREQ>(); else dma_wait<0>();
     __syncthreads();
     if (0 < wave_len) {
       uint4 kf[8];
@@ -463,120 +436,6 @@ void prefill_mfma32_kernel(PrefillArgs a) {
       if (PROF) { prof[0] += t1 - t0; prof[1] += t2 - t1; prof[2] += t3 - t2; prof[5] += 1; }
     };
     const bool late_team = STAGGER && team == 1;  // wave-uniform
-    // PP: the fragments a compute phase works on, read by the load phase in front of it
-    uint4 kfp[8], vfp[8];
-    uint32_t pwp[8];  // (PPMS) the step's probabilities, two to a word
-    auto pp_load = [&](int step, auto stage_c) {
-      constexpr int STAGE = decltype(stage_c)::value;
-      constexpr int NEXT = (STAGE + 1) % NSTAGE;
-      const uint64_t t0 = PROF ? __builtin_readcyclecounter() : 0;
-      uint64_t t1 = t0, t2 = t0;
-      const int in_blk = step & (SLOTS / STEP - 1);
-      const bool more_entries = ((step >> 4) + 1) * SLOTS < kv_len;              // wave-uniform
-      const bool issue_ok = ((BSGL_CUT & 4) == 0) && step + AH < n_steps;        // wave-uniform
-      if (issue_ok) make_src();  // (their row offsets were read one load phase ago)
-      if (((BSGL_CUT & 16) == 0 || step == 0) && blk + step * STEP < wave_len) {
-        // V of this step (read by nobody else any more once both teams have passed this phase) and K of
-        // the next one (whatever the stage holds if there is none: those scores are never used)
-        // (the offsets of the other fragments from the first one's: the chunk index enters them by an
-        // exclusive or, and a register per offset is what this kernel cannot spare)
-        const char* st = smem + STAGE * STEP_BYTES;
-        int k0 = k_off[0], v0 = v_off[0][0], v1 = v_off[1][0];
-        asm volatile("" : "+v"(k0), "+v"(v0), "+v"(v1));
-#pragma unroll
-        for (int kb = 0; kb < 8; ++kb) kfp[kb] = *(const uint4*)(smem + NEXT * STEP_BYTES + (k0 ^ (kb << 5)));
-        if constexpr (!PP_VLATE) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const s16x4_t va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4_t*)(st + (i >> 2) * TILE_BYTES + (v0 ^ ((i & 3) << 6))));
-          const s16x4_t vb = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4_t*)(st + (i >> 2) * TILE_BYTES + (v1 ^ ((i & 3) << 6))));
-          const uint2 va2 = __builtin_bit_cast(uint2, va), vb2 = __builtin_bit_cast(uint2, vb);
-          vfp[i] = make_uint4(va2.x, va2.y, vb2.x, vb2.y);
-        }
-        }
-        if constexpr (PPMS) {
-          // the softmax of this step's scores (made by the compute phase before this one), while the reads travel
-          f32x16& sc = sc_a;
-          if (blk + step * STEP + STEP - 1 > full_until) {  // wave-uniform
-            int t0m = blk + step * STEP + 4 * hi;
-            asm volatile("" : "+v"(t0m));
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sc[r] = (t0m + acc_row(r, 0) <= my_last) ? sc[r] : kNegInf;
-          }
-          const float lmax = max16(sc);
-          if (__any(lmax > m_run + slack_raw)) {
-            float x = lmax, y = lmax;
-            swap32(x, y);
-            const float m_new = fmaxf(m_run, fmaxf(x, y));
-            const float alpha = m_new == kNegInf ? 1.f : fast_exp2((m_run - m_new) * scale_log2e);
-            m_run = m_new;
-            neg_mc = -(m_new == kNegInf ? 0.f : m_new) * scale_log2e;
-            l_run *= alpha;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float ar = __shfl(alpha, acc_row(r, 0) + 4 * hi);
-#pragma unroll
-              for (int db = 0; db < 4; ++db) o_acc[db][r] *= ar;
-            }
-          }
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float p0 = fast_exp2(fmaf(sc[2 * j], scale_log2e, neg_mc));
-            const float p1 = fast_exp2(fmaf(sc[2 * j + 1], scale_log2e, neg_mc));
-            pwp[j] = E::pack2(p0, p1);
-            asm volatile("v_add_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %2" : "+v"(l_run) : "v"(p0), "v"(p1));
-          }
-        }
-      }
-      // This wave's share of step + 2 has landed: the barrier that closes this phase publishes it, and the
-      // step's K is first read two phases on (by the first team; its requests went out AH steps ahead, the
-      // steps after it up to step + AH - 1 may stay in flight; near the end of the stream: everything).
-      if (step + 2 < n_steps) {
-        if (step + AH > n_steps) dma_wait<0>(); else dma_wait<NREQ * (AH - 3)>();
-      }
-      t1 = PROF ? __builtin_readcyclecounter() : 0;
-      // the entries of block b + 1 were asked for at step 16 b + 2 behind that phase's K/V requests; every
-      // request of the wave up to step 16 b + 3 + AH has been waited for by now
-      if (in_blk == AH + 1 && more_entries) {
-        int32_t* half = s_slots + (((step >> 4) + 1) & 1) * SLOTS;
-        uint32_t e[EPT];
-#pragma unroll
-        for (int k = 0; k < EPT; ++k) e[k] = (uint32_t)half[tid + k * NTHR];
-#pragma unroll
-        for (int k = 0; k < EPT; ++k) half[tid + k * NTHR] = entry_off(e[k]);
-      }
-      if (issue_ok) issue_group(step + AH);
-      read_offsets(step + AH + 1);
-      if (in_blk == 2 && more_entries) {
-        const int e = ((step >> 4) + 1) * SLOTS + tid;
-        const uint32_t half = lds_slots + (uint32_t)((((step >> 4) + 1) & 1) * SLOTS * 4) + (uint32_t)wave * 256u;
-#pragma unroll
-        for (int k = 0; k < EPT; ++k)
-          dma_256((const void*)entry_ptr(e + k * NTHR), __builtin_amdgcn_readfirstlane(half + (uint32_t)(k * NTHR * 4)));
-      }
-      t2 = PROF ? __builtin_readcyclecounter() : 0;
-      __syncthreads();
-      if (PROF) { prof[0] += t1 - t0; prof[2] += t2 - t1; prof[1] += __builtin_readcyclecounter() - t2; prof[5] += 1; }
-    };
-    // (PPMS) the compute phase: the next step's scores and this step's PV products, operands in registers
-    auto pp_mma = [&](int step) {
-      if (blk + step * STEP >= wave_len) return;  // (wave-uniform)
-      const uint64_t t3 = PROF ? __builtin_readcyclecounter() : 0;
-      f32x16 sn;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sn[r] = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 8; ++kb) sn = Mma32<Tag>::mm(kfp[kb], qf[kb], sn);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int kk = i >> 2;
-        o_acc[i & 3] = Mma32<Tag>::mm(make_uint4(pwp[4 * kk], pwp[4 * kk + 1], pwp[4 * kk + 2], pwp[4 * kk + 3]), vfp[i], o_acc[i & 3]);
-      }
-      sc_a = sn;
-      if (PROF) prof[3] += __builtin_readcyclecounter() - t3;
-    };
     uint4 kf_cut[8] = {};
     if constexpr ((BSGL_CUT & 16) != 0) {
       load_k(kf_cut, smem);
@@ -587,9 +446,7 @@ void prefill_mfma32_kernel(PrefillArgs a) {
       constexpr int STAGE = decltype(stage_c)::value;
       constexpr int NEXT = (STAGE + 1) % NSTAGE;
       // (the late team has run this step's head already, between the halves of the step before)
-      if constexpr (!PP) {
-        if (!late_team || step == 0) top(step);
-      }
+      if (!late_team || step == 0) top(step);
       const uint64_t t3 = PROF ? __builtin_readcyclecounter() : 0;
       const char* st = smem + STAGE * STEP_BYTES;
       if (blk + step * STEP >= wave_len) {  // nothing this wave's rows may see (wave-uniform)
@@ -600,17 +457,13 @@ void prefill_mfma32_kernel(PrefillArgs a) {
       // K fragments of step + 1 (whatever the stage holds if there is no such step: the scores
       // made of them are then never used); they travel while the maximum is looked at
       uint4 kf[8];
-      if constexpr (PP) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) kf[i] = kfp[i];
-      } else if constexpr ((BSGL_CUT & 16) != 0) {  // timing cut: no LDS reads in the loop
+      if constexpr ((BSGL_CUT & 16) != 0) {  // timing cut: no LDS reads in the loop
 #pragma unroll
         for (int i = 0; i < 8; ++i) kf[i] = kf_cut[i];
       } else {
         load_k(kf, smem + NEXT * STEP_BYTES);
       }
 
-      if constexpr (PP_PRIO) __builtin_amdgcn_s_setprio(1);
       const bool step_masked = blk + step * STEP + STEP - 1 > full_until;  // wave-uniform
       if (step_masked) {
         int t0m = blk + step * STEP + 4 * hi;
@@ -645,7 +498,6 @@ void prefill_mfma32_kernel(PrefillArgs a) {
       // the vector issue for 8 of its 32 cycles; the gap takes one or two exponentials (8
       // cycles each) and a few 4-cycle instructions.
       auto v_frag = [&](int i) {  // V fragment of PV product i: tile i >> 2, value columns 32 (i & 3) ..
-        if constexpr (PP && !PP_VLATE) return vfp[i];
         if constexpr ((BSGL_CUT & 16) != 0) return kf_cut[i];
         const s16x4_t va = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (__attribute__((address_space(3))) s16x4_t*)(st + (i >> 2) * TILE_BYTES + v_off[0][i & 3]));
@@ -707,35 +559,9 @@ void prefill_mfma32_kernel(PrefillArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if constexpr (PP_PRIO) __builtin_amdgcn_s_setprio(0);
       if (PROF) prof[3] += __builtin_readcyclecounter() - t3;
     };
     static_assert(NSTAGE == 4 || NSTAGE == 8, "the step loop below is unrolled over the ring");
-    if constexpr (PP) {
-      // every wave passes 2 n_steps + 1 barriers: the second team idles through the first phase, the
-      // first team through the last
-      auto pp_step = [&](int step, auto stage_c, f32x16& sc, f32x16& sn) {
-        pp_load(step, stage_c);
-        if constexpr ((BSGL_CUT & 32) == 0) {  // (32: timing cut, load phases only)
-          if constexpr (PPMS) pp_mma(step); else do_step(step, stage_c, sc, sn);
-        }
-        const uint64_t t4 = PROF ? __builtin_readcyclecounter() : 0;
-        __syncthreads();
-        if (PROF) prof[1] += __builtin_readcyclecounter() - t4;
-      };
-      if (team == 1) __syncthreads();
-      for (int step = 0; step < n_steps; step += NSTAGE) {
-        pp_step(step, std::integral_constant<int, 0>{}, sc_a, sc_b);
-        if (step + 1 < n_steps) pp_step(step + 1, std::integral_constant<int, 1>{}, sc_b, sc_a);
-        if (step + 2 < n_steps) pp_step(step + 2, std::integral_constant<int, 2>{}, sc_a, sc_b);
-        if (step + 3 < n_steps) pp_step(step + 3, std::integral_constant<int, 3>{}, sc_b, sc_a);
-        if (step + 4 < n_steps) pp_step(step + 4, std::integral_constant<int, 4>{}, sc_a, sc_b);
-        if (step + 5 < n_steps) pp_step(step + 5, std::integral_constant<int, 5>{}, sc_b, sc_a);
-        if (step + 6 < n_steps) pp_step(step + 6, std::integral_constant<int, 6>{}, sc_a, sc_b);
-        if (step + 7 < n_steps) pp_step(step + 7, std::integral_constant<int, 7>{}, sc_b, sc_a);
-      }
-      if (team == 0) __syncthreads();
-    } else
     for (int step = 0; step < n_steps; step += NSTAGE) {
       do_step(step, std::integral_constant<int, 0>{}, sc_a, sc_b);
       if (step + 1 < n_steps) do_step(step + 1, std::integral_constant<int, 1>{}, sc_b, sc_a);
