@@ -128,6 +128,11 @@ class _ForwardWorker:
     def submit(self, mode: str, fb: SimplifiedForwardBatch, batch, logits_rows, ids_host) -> None:
         # everything the batch needs was enqueued on the caller's stream: the forward stream waits for
         # it on the device (the reference waits on the host instead, overlap_worker.py:83)
+        # (the batch's tensors were allocated on the caller's stream: the allocator must not hand their
+        # memory out again before the forward stream is done with them, whoever drops them first)
+        for t in list(vars(fb).values()) + [logits_rows]:
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(self.stream)
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(self.loop.device))
         self.inbox.put((mode, fb, batch, logits_rows, ids_host, ready))

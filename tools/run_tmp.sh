@@ -1,9 +1,12 @@
 set -u
 cd $GRAFT_REPO_ROOT
-bash tools/prof_bench.sh r3p_bench > gpurun_out/r3p_bench.txt 2>&1 && echo "prof_bench ok" && \
-bash tools/prof_prefill.sh r3p_ext --reps 100 > gpurun_out/r3p_ext.txt 2>&1 && echo "prof_prefill ok" && \
-bash tools/pmc_extend.sh r3p_pmc > gpurun_out/r3p_pmc.txt 2>&1 && echo "pmc_extend ok" && \
-bash tools/pmc_traffic.sh r3p_traffic > gpurun_out/r3p_traffic.txt 2>&1 && echo "pmc_traffic ok" && \
-(cd $GRAFT_REPO_ROOT && timeout -k 10 600 python bench.py > gpurun_out/r3p_benchline.json 2> gpurun_out/r3p_benchline.err) && echo "bench ok"
-tail -3 gpurun_out/r3p_bench.txt gpurun_out/r3p_ext.txt gpurun_out/r3p_pmc.txt gpurun_out/r3p_traffic.txt | cut -c1-400
-cut -c1-3000 gpurun_out/r3p_benchline.json
+mkdir -p gpurun_out/r4c
+lib=baby-sglang_amd/libbsgl_attn.so
+cp $lib /tmp/tree.so
+cp variants/libbsgl_sp1.so $lib
+timeout -k 10 400 python -u -m pytest tests/test_gpu_parity.py tests/test_gpu_caller_shapes.py tests/test_gpu_bench_sizes.py -m gpu -x -q --timeout 100 --timeout-method thread -k "extend or prefill or chunk" > gpurun_out/r4c/t.txt 2>&1
+rc=$?
+tail -5 gpurun_out/r4c/t.txt
+cp /tmp/tree.so $lib
+[ $rc = 0 ] || exit $rc
+bash tools/run_ab.sh r4c 2 1 "" sp1 sp2 nosplit
