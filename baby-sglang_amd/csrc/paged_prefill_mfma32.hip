@@ -34,7 +34,8 @@
 // request of the step loop re-reads the rows of the request's FIRST tokens (same instructions and LDS
 // writes, but served by the CU's own cache: what the traffic between L2 and the CU costs), 512 = the
 // whole K/V stream of the workgroup is run through TWICE (one prologue, one epilogue: the difference
-// to the plain launch is what a pass over the stream costs without them).
+// to the plain launch is what a pass over the stream costs without them), 1024 = no mask and no running-maximum
+// check at the head of a step's body (after step 0).
 #ifndef BSGL_CUT
 #define BSGL_CUT 0
 #endif
@@ -465,7 +466,7 @@ void prefill_mfma32_kernel(PrefillArgs a) {
       }
 
       const bool step_masked = blk + step * STEP + STEP - 1 > full_until;  // wave-uniform
-      if (step_masked) {
+      if (((BSGL_CUT & 1024) == 0) && __builtin_expect(step_masked, 0)) {  // (rare: the block's diagonal steps)
         int t0m = blk + step * STEP + 4 * hi;
         asm volatile("" : "+v"(t0m));
 #pragma unroll
@@ -473,7 +474,7 @@ void prefill_mfma32_kernel(PrefillArgs a) {
       }
       // lazy running maximum: see paged_prefill_mfma.hip
       const float lmax = step_masked ? max16(sc) : lmax_nx;
-      if (__any(lmax > m_run + slack_raw)) {
+      if (((BSGL_CUT & 1024) == 0 || step == 0) && __builtin_expect(__any(lmax > m_run + slack_raw), 0)) {  // (rare after the first steps)
         float x = lmax, y = lmax;
         swap32(x, y);  // the partner lane holds the position's other 16 tokens
         const float m_new = fmaxf(m_run, fmaxf(x, y));
