@@ -39,37 +39,43 @@ __global__ void prefill_cu_kernel(ExpandArgs a) {
   const int tid = threadIdx.x;
   const int per = (a.batch + 255) / 256;
   const int lo = min(tid * per, a.batch), hi = min(lo + per, a.batch);
-  const int64_t br = a.blk_rows > 0 ? a.blk_rows : 16;
-  const int64_t gb = a.grp_blocks > 0 ? a.grp_blocks : 1;
+  // (lengths are bounded by the number of q rows, an int: 32-bit unsigned divisions, a fraction of the
+  // instructions of 64-bit ones)
+  const uint32_t br = a.blk_rows > 0 ? (uint32_t)a.blk_rows : 16u;
+  const uint32_t gb = a.grp_blocks > 0 ? (uint32_t)a.grp_blocks : 1u;
+  auto groups_of = [&](int64_t e) { return (int64_t)((((uint32_t)e + br - 1) / br + gb - 1) / gb); };
   int64_t sum = 0, blocks = 0;
   for (int i = lo; i < hi; ++i) {
     const int64_t e = min(max((int64_t)0, a.extended_lens[i]), (int64_t)a.total_q_tokens);  // (bounded: the sums cannot overflow)
     sum += e;
-    blocks += ((e + br - 1) / br + gb - 1) / gb;
+    blocks += groups_of(e);
   }
-  s_ext[tid] = sum;
-  s_blk[tid] = blocks;
-  __syncthreads();
-  if (tid == 0) {
-    int64_t run = 0, brun = 0;
-    for (int i = 0; i < 256; ++i) {
-      const int64_t v = s_ext[i], b = s_blk[i];
-      s_ext[i] = run;
-      s_blk[i] = brun;
-      run += v;
-      brun += b;
-    }
-    a.cu_ext[a.batch] = run;
-    if (a.cu_blk != nullptr) a.cu_blk[a.batch] = brun;
+  // exclusive scan over the 256 threads' partial sums: inside a wave by shuffles, across the four waves
+  // through LDS (one thread walking all 256 entries took 4 of this launch's 8 microseconds)
+  const int lane = tid & 63, wave = tid >> 6;
+  int64_t inc_e = sum, inc_b = blocks;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int64_t oe = __shfl_up(inc_e, d), ob = __shfl_up(inc_b, d);
+    if (lane >= d) { inc_e += oe; inc_b += ob; }
   }
+  if (lane == 63) { s_ext[wave] = inc_e; s_blk[wave] = inc_b; }
   __syncthreads();
-  int64_t run = s_ext[tid], brun = s_blk[tid];
+  int64_t run = inc_e - sum, brun = inc_b - blocks;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    if (w < wave) { run += s_ext[w]; brun += s_blk[w]; }
+  }
+  if (tid == 255) {
+    a.cu_ext[a.batch] = run + sum;
+    if (a.cu_blk != nullptr) a.cu_blk[a.batch] = brun + blocks;
+  }
   for (int i = lo; i < hi; ++i) {
     const int64_t e = min(max((int64_t)0, a.extended_lens[i]), (int64_t)a.total_q_tokens);  // (bounded: the sums cannot overflow)
     a.cu_ext[i] = run;
     if (a.cu_blk != nullptr) a.cu_blk[i] = brun;
     run += e;
-    brun += ((e + br - 1) / br + gb - 1) / gb;
+    brun += groups_of(e);
   }
 }
 
