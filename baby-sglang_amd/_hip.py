@@ -35,6 +35,8 @@ COMM_ID_BYTES = 128
 DECODE_AUTO, DECODE_VALU, DECODE_MFMA = 0, 1, 2
 DECODE_FUSE_KV_WRITE = 0x100  # caller asserts: out_cache_loc slots belong to their own request only
 DECODE_UNIFORM_SPLITS = 0x200  # exactly n_splits equal pieces per request instead of length-balanced ones
+PREFILL_LIST_READY = 0x400  # paged_prefill: the workspace still holds this batch's work list
+knob_epoch = 0  # bumped by set_knob: a cached work list was made under the knobs of its epoch
 
 _DTYPE_CODE = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
 _DTYPE_CODE_GET = _DTYPE_CODE.get
@@ -161,8 +163,10 @@ def set_knob(name: str, value: int) -> int:
     """Replace one of the library's tuning knobs (named like its environment variable, e.g.
     ``BSGL_MFMA_WAVES``); returns the value it had.  The library reads the environment once per
     process, so this is how a test or a tuning script changes a knob afterwards."""
+    global knob_epoch
     prev = ctypes.c_int32(0)
     _check(lib.bsgl_debug_set_knob(name.encode(), int(value), ctypes.byref(prev)), "bsgl_debug_set_knob")
+    knob_epoch += 1
     return int(prev.value)
 
 
@@ -429,8 +433,10 @@ def paged_prefill(
     variant: int = DECODE_AUTO,
     out: Optional[torch.Tensor] = None,
     workspace: Optional[torch.Tensor] = None,
+    list_ready: bool = False,
 ) -> torch.Tensor:
-    """Extend attention over cached prefixes; returns [T, Hq * D] (T rows of q)."""
+    """Extend attention over cached prefixes; returns [T, Hq * D] (T rows of q).  ``list_ready``: ``workspace``
+    still holds the work list an earlier call made for this very batch (``BSGL_PREFILL_LIST_READY``)."""
     _need_gpu(q, k_slab, v_slab, req_to_token, req_pool_indices, seq_lens, prefix_lens, extended_lens)
     q = _rows(q)
     total_q, hq, dim = q.shape
@@ -458,7 +464,7 @@ def paged_prefill(
         k_slab.data_ptr(), v_slab.data_ptr(), k_slab.stride(0), k_slab.shape[0],
         req_to_token.data_ptr(), req_to_token.stride(0), req_to_token.shape[0], req_to_token.shape[1],
         i64[0].data_ptr(), i64[1].data_ptr(), i64[2].data_ptr(), i64[3].data_ptr(),
-        batch, total_q, hq, hkv, dim, scale, _dtype_code(q), variant,
+        batch, total_q, hq, hkv, dim, scale, _dtype_code(q), variant | (PREFILL_LIST_READY if list_ready else 0),
         workspace.data_ptr(), workspace.numel() * workspace.element_size(),
         _stream_ptr(q.device),
     )  # fmt: skip

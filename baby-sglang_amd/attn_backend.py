@@ -26,6 +26,7 @@ from __future__ import annotations
 import collections
 import os
 import threading
+import weakref
 
 import torch
 
@@ -311,12 +312,26 @@ class SimpleAttentionBackend:
     def _prefill_attention(q, forward_batch: SimplifiedForwardBatch, layer_id: int):
         k_slab, v_slab = forward_batch.token_to_kv_pool.get_kv_buffer(layer_id)
         workspace = None
+        list_ready = False
         if q.is_cuda and q.dim() == 3:
             # the extend launch's work list lives in a per-stream buffer instead of a fresh allocation per layer call
             need = _hip.prefill_workspace_bytes(int(forward_batch.req_pool_indices.shape[0]), q.shape[0], q.shape[1], q.shape[2])
             stream = _hip.current_stream_handle(q.device.index)
             workspace = SimpleAttentionBackend._prefill_workspaces.get(
                 (q.device, stream), need, lambda n: torch.empty(max(n, 1 << 16), dtype=torch.uint8, device=q.device))
+            # ... and is made once per batch, not once per layer: the layers of a model call the backend with
+            # ONE batch descriptor (qwen2.py:292-315), so from the second layer on the list of the first is
+            # still in the buffer.  Whose list it holds is kept ON the buffer, by identity (weak references:
+            # the note must not keep a batch alive): the batch object, its extended_lens tensor, then the
+            # shape of q, the dtype, the kv heads and the knobs' epoch -- and the layer that used it last: only
+            # a LATER layer takes the list over, so a caller that keeps one batch object and rewrites its
+            # tensors in place from step to step gets a new list with the first layer of every forward.
+            ext = forward_batch.extended_lens
+            facts = (tuple(q.shape), q.dtype, k_slab.shape[1], _hip.knob_epoch)
+            held = getattr(workspace, "_bsgl_list_of", None)
+            list_ready = (held is not None and held[0]() is forward_batch and held[1]() is ext and held[2] == facts
+                          and layer_id > held[3])
+            workspace._bsgl_list_of = (weakref.ref(forward_batch), weakref.ref(ext), facts, layer_id)
         return _hip.paged_prefill(
             q,
             k_slab,
@@ -327,4 +342,5 @@ class SimpleAttentionBackend:
             forward_batch.prefix_lens,
             forward_batch.extended_lens,
             workspace=workspace,
+            list_ready=list_ready,
         )

@@ -632,8 +632,11 @@ int bsgl_paged_prefill(void* out, int64_t out_row_stride, const void* q, int64_t
   if (kind == BSGL_DECODE_MFMA && !mfma_ok) return fail(BSGL_ERR_UNSUPPORTED, "matrix-core extend: %s", why);
   if (kind != BSGL_DECODE_VALU && mfma_ok) {
     ex.row_req = nullptr;  // only the running sums are needed
-    hipError_t e = bsgl::launch_prefill_expand(ex, (hipStream_t)stream);
-    if (e != hipSuccess) return hip_fail("prefill running-sum launch", e);
+    hipError_t e = hipSuccess;
+    if ((variant & BSGL_PREFILL_LIST_READY) == 0) {  // (else: an earlier call for this batch left them in the workspace)
+      e = bsgl::launch_prefill_expand(ex, (hipStream_t)stream);
+      if (e != hipSuccess) return hip_fail("prefill running-sum launch", e);
+    }
     e = bsgl::launch_prefill_mfma(pa, (hipStream_t)stream);
     if (e != hipSuccess) return hip_fail("prefill launch", e);
     return BSGL_OK;

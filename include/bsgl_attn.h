@@ -60,6 +60,14 @@ extern "C" {
  * sum(seq_lens) / (batch * ceil(n_splits / 2)) tokens, so that ragged batches
  * load every workgroup alike.  Results agree to rounding either way. */
 #define BSGL_DECODE_UNIFORM_SPLITS 0x200
+/* OR into `variant` of bsgl_paged_prefill when `workspace` still holds the work list (the running sums
+ * of extended_lens and of the requests' block groups) that an earlier call of bsgl_paged_prefill wrote
+ * there for the SAME batch -- same batch, total_q_tokens, contents of extended_lens, head counts, head_dim,
+ * dtype and tuning knobs -- and nothing has written the workspace since: the launch that makes the list is
+ * then left out.  That is every layer after the first of one model forward (the reference calls its
+ * backend once per layer with one batch descriptor, qwen2.py:292-315): 4.7 us less per layer call.
+ * Ignored where the generic path runs (it rebuilds its row list every time). */
+#define BSGL_PREFILL_LIST_READY 0x400
 
 /* ABI version of this header (bumped on any signature change). */
 int bsgl_abi_version(void);
