@@ -66,11 +66,13 @@ def parse_args():
                     help="ranks per tensor-parallel group (0 = N: ONE group of all ranks, kv heads first, then sequence "
                          "slices inside a kv head).  A smaller value runs N / tp such groups side by side as replicas on "
                          "different requests (--tp 2: each rank owns a whole kv head, no sequence slices)")
-    ap.add_argument("--collectives", choices=["auto", "torch", "capi"], default="auto",
+    ap.add_argument("--collectives", choices=["auto", "torch", "capi"], default="torch",
                     help="N > 1: torch = torch.distributed (RCCL) issued from Python per layer; capi = the library's own "
                          "RCCL communicator (bsgl_all_gather enqueued on the launch stream, no per-call work objects; "
                          "kv-head shards only); auto = capi when its communicator comes up on every rank and its first "
-                         "gather equals torch.distributed's, torch otherwise")
+                         "gather equals torch.distributed's, torch otherwise.  The default is torch: the library's "
+                         "communicator has never come up between two GPUs (one GPU per box where this was built), "
+                         "and a first run should not depend on it")
     ap.add_argument("--tp-graph", action="store_true",
                     help="N > 1 with capi collectives: replay the whole step, collectives included, from one HIP graph")
     ap.add_argument("--launch-timeout", type=float, default=1500.0,
