@@ -365,8 +365,10 @@ void prefill_dual_kernel(PrefillArgs a) {
   // Scores of half hq from the K fragments in kf.  In the gaps: the remaining exponentials of half he (none:
   // he < 0; its first NE_PV were made in the PV block before) and their packing into the A operand of its
   // PV products; the first three V fragments of that PV block (stage vst) are asked for on the way.
-  auto block_qe = [&](auto hqc, auto hec, auto vc, const char* vst) __attribute__((always_inline)) {
+  auto block_qe = [&](auto hqc, auto hec, auto vc, auto kloc, auto dmac, const char* vst, const char* kst, bool issue_ok) __attribute__((always_inline)) {
     constexpr bool with_v = decltype(vc)::value != 0;
+    constexpr int k_lo = decltype(kloc)::value;  // K fragments 0 .. k_lo - 1 of the NEXT step (stage kst) behind their last use
+    constexpr int dma = decltype(dmac)::value;   // -1, or 64 * ring stage + 8 * request + gap: one K/V request of this wave
     constexpr int hq = decltype(hqc)::value;
     constexpr int he = decltype(hec)::value;
     constexpr int hx = he < 0 ? 0 : he;
@@ -397,6 +399,10 @@ void prefill_dual_kernel(PrefillArgs a) {
         if constexpr (kb == 6) pk(6);
       }
       if constexpr (with_v && kb >= 5) vf[kb - 5] = v_frag(vst, kb - 5);
+      if constexpr (kb < k_lo && (BSGL_CUT & 16) == 0) kf[kb] = *(const uint4*)(kst + k_off[kb]);
+      if constexpr (dma >= 0 && (dma & 7) == kb) {
+        if (issue_ok) issue_one((dma >> 3) & 7, dst_of(dma >> 6, (dma >> 3) & 7));
+      }
       __builtin_amdgcn_sched_barrier(0);
     });
     if constexpr (he >= 0) pk(7);
@@ -407,9 +413,9 @@ void prefill_dual_kernel(PrefillArgs a) {
   // mask, the largest score, the check against its reference, and its first NE_PV exponentials; where kst is
   // given the K fragments of the next score block from stage kst; where dma_stage >= 0 this wave's four K/V
   // requests (addresses in src4) into that ring stage.
-  auto block_pv = [&](auto hpc, auto hoc, auto kc, auto dc, const char* st, const char* kst, int step_o, bool issue_ok) __attribute__((always_inline)) {
-    constexpr bool with_k = decltype(kc)::value != 0;
-    constexpr int dma_stage = decltype(dc)::value;
+  auto block_pv = [&](auto hpc, auto hoc, auto kc, auto dmac, const char* st, const char* kst, int step_o, bool issue_ok) __attribute__((always_inline)) {
+    constexpr int k_from = decltype(kc)::value;  // K fragments k_from .. 7 of the next score block (stage kst), one per gap; 8: none
+    constexpr int dma = decltype(dmac)::value;   // as in block_qe
     constexpr int hp = decltype(hpc)::value;
     constexpr int ho = decltype(hoc)::value;
     float mx0 = kNegInf, mx1 = kNegInf, mx2 = kNegInf;
@@ -420,9 +426,9 @@ void prefill_dual_kernel(PrefillArgs a) {
       o_acc[hp][i & 3] = MmaD<Tag>::mm(make_uint4(pw[hp][4 * kk], pw[hp][4 * kk + 1], pw[hp][4 * kk + 2], pw[hp][4 * kk + 3]),
                                        vf[i % 4], o_acc[hp][i & 3]);
       if constexpr (i + 3 < 8) vf[(i + 3) % 4] = v_frag(st, i + 3);
-      if constexpr (with_k && (BSGL_CUT & 16) == 0) kf[i] = *(const uint4*)(kst + k_off[i]);
-      if constexpr (dma_stage >= 0 && i < 4) {
-        if (issue_ok) issue_one(i, dst_of(dma_stage < 0 ? 0 : dma_stage, i));
+      if constexpr (k_from + i < 8 && (BSGL_CUT & 16) == 0) kf[k_from + i] = *(const uint4*)(kst + k_off[k_from + i]);
+      if constexpr (dma >= 0 && (dma & 7) == i) {
+        if (issue_ok) issue_one((dma >> 3) & 7, dst_of(dma >> 6, (dma >> 3) & 7));
       }
       // (as instructions of their own: the compiler otherwise pairs the sums into packed adds and parks them)
       if constexpr ((BSGL_CUT & 8) == 0) {
@@ -460,8 +466,8 @@ void prefill_dual_kernel(PrefillArgs a) {
   if (any_rows) {
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) kf[kb] = *(const uint4*)(smem + k_off[kb]);
-    block_qe(ic<0>{}, ic<-1>{}, ic<0>{}, smem);
-    block_qe(ic<1>{}, ic<-1>{}, ic<1>{}, smem);
+    block_qe(ic<0>{}, ic<-1>{}, ic<0>{}, ic<0>{}, ic<-1>{}, smem, smem, false);
+    block_qe(ic<1>{}, ic<-1>{}, ic<1>{}, ic<0>{}, ic<-1>{}, smem, smem, false);
     mask_scores(ic<0>{}, 0);
     check_max(ic<0>{}, max16(sc[0]));
 #pragma unroll
@@ -469,7 +475,7 @@ void prefill_dual_kernel(PrefillArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) pw[0][j] = E::pack2(pf[0][2 * j], pf[0][2 * j + 1]);
     // (K of step 1 on the way; whatever the stage holds if there is no step 1: those scores get masked)
-    block_pv(ic<0>{}, ic<1>{}, ic<1>{}, ic<-1>{}, smem, smem + STEP_BYTES, 0, false);
+    block_pv(ic<0>{}, ic<1>{}, ic<0>{}, ic<-1>{}, smem, smem + STEP_BYTES, 0, false);
   }
 
   // The head of a step: this wave's share of step + 2 has landed, the workgroup barrier (everybody's has,
@@ -527,14 +533,15 @@ void prefill_dual_kernel(PrefillArgs a) {
       }
       return;
     }
-    block_qe(ic<0>{}, ic<1>{}, ic<1>{}, st);                                         // block 1 (kf: K of step + 1)
+    constexpr int KLO = 4;  // K fragments of step + 2 fetched in block 3 (the rest in block 4)
+    block_qe(ic<0>{}, ic<1>{}, ic<1>{}, ic<0>{}, ic<64 * DSTAGE + 8 * 0 + 4>{}, st, st, issue_ok);  // block 1 (kf: K of step + 1)
     if (PROF) tb1 = __builtin_readcyclecounter();
-    block_pv(ic<1>{}, ic<0>{}, ic<0>{}, ic<DSTAGE>{}, st, st, step + 1, issue_ok);   // block 2
+    block_pv(ic<1>{}, ic<0>{}, ic<8>{}, ic<64 * DSTAGE + 8 * 1 + 6>{}, st, st, step + 1, issue_ok);  // block 2
     if (PROF) tb2 = __builtin_readcyclecounter();
     if (step + 1 < n_steps) {  // wave-uniform
-      block_qe(ic<1>{}, ic<0>{}, ic<1>{}, sx);                                       // block 3
+      block_qe(ic<1>{}, ic<0>{}, ic<1>{}, ic<KLO>{}, ic<64 * DSTAGE + 8 * 2 + 4>{}, sx, sy, issue_ok);  // block 3
       if (PROF) tb3 = __builtin_readcyclecounter();
-      block_pv(ic<0>{}, ic<1>{}, ic<1>{}, ic<-1>{}, sx, sy, step + 1, false);        // block 4 (K of step + 2 on the way)
+      block_pv(ic<0>{}, ic<1>{}, ic<KLO>{}, ic<64 * DSTAGE + 8 * 3 + 6>{}, sx, sy, step + 1, issue_ok);  // block 4
       if (PROF) {  // (phase sums: head of the step, blocks 1, 2, 3, whole body)
         const uint64_t te = __builtin_readcyclecounter();
         prof[0] += t3 - t0; prof[1] += tb1 - t3; prof[2] += tb2 - tb1; prof[4] += tb3 - tb2; prof[3] += te - t3; prof[5] += 1;
