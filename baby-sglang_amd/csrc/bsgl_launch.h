@@ -34,7 +34,6 @@ enum Knob : int {
   kKnobPrefillLdsPad,   // BSGL_PREFILL_LDS_PAD: extra LDS bytes per extend workgroup (lowers occupancy)
   kKnobP2PWaitMs,       // BSGL_P2P_WAIT_MS: how long a one-shot all-reduce waits for a peer (default 10000)
   kKnobDecodeWhole,     // BSGL_DECODE_WHOLE: requests up to this many tokens stay in one piece where several waves share a piece (default 256)
-  kKnobPrefillDual,     // BSGL_PREFILL_DUAL: 1 = the one-wave-per-SIMD extend kernel on 128-position blocks
   kKnobCount
 };
 int knob(Knob k);
@@ -236,9 +235,5 @@ hipError_t launch_prefill_mfma(const PrefillArgs& a, hipStream_t stream);
 // launch_prefill_mfma picks it where it applies
 bool prefill_mfma32_supported(const PrefillArgs& a);
 hipError_t launch_prefill_mfma32(const PrefillArgs& a, hipStream_t stream);
-// one wave per SIMD, two interleaved row halves per wave (128-position blocks): launch_prefill_mfma32
-// hands over where kKnobPrefillDual asks for it
-bool prefill_dual_supported(const PrefillArgs& a);
-hipError_t launch_prefill_dual(const PrefillArgs& a, hipStream_t stream);
 
 }  // namespace bsgl

@@ -47,7 +47,7 @@ constexpr KnobDef kKnobDefs[kKnobCount] = {
     {"BSGL_PREFILL_GROUP", 0},    {"BSGL_MFMA_NT", 1},             {"BSGL_MFMA_STAGES", 2},
     {"BSGL_MFMA_HPT", 1},         {"BSGL_MFMA_WAVES", 0},          {"BSGL_PREFILL_RT", 0},
     {"BSGL_PREFILL_16", 0},       {"BSGL_PREFILL_LDS_PAD", 0},     {"BSGL_P2P_WAIT_MS", 10000},
-    {"BSGL_DECODE_WHOLE", 256},   {"BSGL_PREFILL_DUAL", 0},
+    {"BSGL_DECODE_WHOLE", 256},
 };
 std::atomic<int> g_knobs[kKnobCount];
 std::once_flag g_knobs_once;
@@ -588,7 +588,7 @@ int bsgl_paged_prefill(void* out, int64_t out_row_stride, const void* q, int64_t
     const int forced = bsgl::knob(bsgl::kKnobPrefillBlk);  // tuning override
     if (forced == 16 || forced == 64) pa.blk_rows = forced;
     // (128: two four-wave teams share a K/V stream; only where the 32x32x16 kernel applies)
-    if ((forced == 128 || bsgl::knob(bsgl::kKnobPrefillDual) == 1) && n_kv_heads > 0 && n_q_heads / n_kv_heads >= 2) pa.blk_rows = 128;
+    if (forced == 128 && n_kv_heads > 0 && n_q_heads / n_kv_heads >= 2) pa.blk_rows = 128;
   }
   ex.blk_rows = pa.blk_rows;
   // Groups of up to 8 consecutive blocks of a request share an XCD (and with it an L2).  The grid

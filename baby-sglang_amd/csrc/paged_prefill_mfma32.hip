@@ -627,7 +627,6 @@ bool prefill_mfma32_supported(const PrefillArgs& a) {
 // the grid of paged_prefill_mfma.hip's launch with 2 (64-position blocks) or 8 (16-position
 // blocks) q heads per workgroup
 hipError_t launch_prefill_mfma32(const PrefillArgs& a, hipStream_t stream) {
-  if (knob(kKnobPrefillDual) == 1 && prefill_dual_supported(a)) return launch_prefill_dual(a, stream);
   const int group = a.n_q_heads / a.n_kv_heads;
   const int hpw = a.blk_rows >= 64 ? 2 : 8;
   const int n_z = (group + hpw - 1) / hpw;

@@ -8,7 +8,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 csrc=$root/baby-sglang_amd/csrc
 mkdir -p "$root/variants"
 extra=""
-case $src in paged_prefill_mfma*.hip) extra="-fno-honor-nans";; paged_prefill_dual.hip) extra="-fno-honor-nans"; [ "${NO_VGPR_FORM:-0}" = 1 ] || extra="$extra -mllvm -amdgpu-mfma-vgpr-form";; esac
+case $src in paged_prefill_mfma*.hip) extra="-fno-honor-nans";; esac
 obj=$root/variants/${src%.hip}_$name.o
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -fno-gpu-rdc $extra "$@" -c "$csrc/$src" -o "$obj"
 others=$(cd "$csrc" && ls *.o | grep -v "^${src%.hip}.o$" | sed "s|^|$csrc/|")

@@ -1,5 +1,7 @@
 // What does one gap between two 32x32x16 matrix products cost with a given set of filler instructions,
-// one wave per SIMD?  (tuning aid: build with tools/ubench_gap.sh, run on the GPU box; prints cycles per product)
+// one wave per SIMD?  Tuning aid, not part of the library: prints cycles per product for a list of gap contents.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-honor-nans [-mllvm -amdgpu-mfma-vgpr-form] tools/ubench_gap.hip -o ubench_gap
+// (with the option the products' accumulators live in vector registers; run the binary on the GPU box)
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
