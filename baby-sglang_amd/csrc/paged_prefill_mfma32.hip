@@ -76,9 +76,9 @@ __device__ __forceinline__ constexpr int acc_row(int r, int hi) { return (r & 3)
 // TEAMS: 1 = four waves, 64 positions x 2 q heads.  2 = eight waves, TWO such teams on consecutive
 // 64-position halves of a 128-position block that share one K/V stream (one workgroup per CU, two
 // waves per SIMD): half the K/V requests and half the bytes from L2 per product.
+// one block slot of the launch (block_id: its index in the launch order); the kernel below is its only caller
 template <typename Tag, int PW, bool PROF, int TEAMS = 1>
-__global__ __launch_bounds__(256 * TEAMS) __attribute__((amdgpu_waves_per_eu(2)))
-void prefill_mfma32_kernel(PrefillArgs a) {
+__device__ __forceinline__ void prefill_mfma32_item(const PrefillArgs& a, const unsigned block_id) {
   using E = Elem<Tag>;
   static_assert(TEAMS == 1 || (TEAMS == 2 && PW == 32), "teams are halves of a 128-position block");
   constexpr int D = 128;
@@ -132,8 +132,8 @@ void prefill_mfma32_kernel(PrefillArgs a) {
   // (the launch order of paged_prefill_mfma.hip: index = 8 * slot + xcd)
   const int n_z = (G + HPW - 1) / HPW;
   const int per_group = a.grp_blocks * n_z;
-  const unsigned slot = blockIdx.x >> 3;
-  const int64_t g = (int64_t)(slot / (unsigned)per_group) * 8 + (blockIdx.x & 7);
+  const unsigned slot = block_id >> 3;
+  const int64_t g = (int64_t)(slot / (unsigned)per_group) * 8 + (block_id & 7);
   if (g >= a.cu_blk[a.batch] * a.n_kv_heads) return;
   const int within = (int)(slot % (unsigned)per_group);
   const int kvh = (int)(g % a.n_kv_heads);
@@ -612,10 +612,16 @@ void prefill_mfma32_kernel(PrefillArgs a) {
     prof[7] = (__builtin_readcyclecounter() - t_entry) & 0xffffffffu;
     prof[6] |= (uint64_t)(prof[7] - (t_loop_end - t_entry)) << 32;
     prof[7] |= ((__builtin_amdgcn_s_memrealtime() - rt_entry) & 0xffffffffu) << 32;
-    uint64_t* dst = a.prof + 8 * ((uint64_t)blockIdx.x * WAVES + wave);
+    uint64_t* dst = a.prof + 8 * ((uint64_t)block_id * WAVES + wave);
 #pragma unroll
     for (int i = 0; i < 8; ++i) dst[i] = prof[i];
   }
+}
+
+template <typename Tag, int PW, bool PROF, int TEAMS = 1>
+__global__ __launch_bounds__(256 * TEAMS) __attribute__((amdgpu_waves_per_eu(2)))
+void prefill_mfma32_kernel(PrefillArgs a) {
+  prefill_mfma32_item<Tag, PW, PROF, TEAMS>(a, blockIdx.x);
 }
 
 }  // namespace
