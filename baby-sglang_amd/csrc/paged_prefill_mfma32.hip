@@ -455,6 +455,10 @@ __device__ __forceinline__ void prefill_mfma32_item(const PrefillArgs& a, const 
         return;
       }
 
+      // The body runs at raised priority (four waves: the SIMD's other wave belongs to another workgroup and
+      // is wherever it is): where both waves have an instruction ready, the one inside its products goes first
+      // and the one at the head of its step (wait, barrier, requests) fills in.  + 0.6 to + 1.8 % by shape.
+      if constexpr (TEAMS == 1) __builtin_amdgcn_s_setprio(2);
       // K fragments of step + 1 (whatever the stage holds if there is no such step: the scores
       // made of them are then never used); they travel while the maximum is looked at
       uint4 kf[8];
@@ -560,6 +564,7 @@ __device__ __forceinline__ void prefill_mfma32_item(const PrefillArgs& a, const 
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      if constexpr (TEAMS == 1) __builtin_amdgcn_s_setprio(0);
       if (PROF) prof[3] += __builtin_readcyclecounter() - t3;
     };
     static_assert(NSTAGE == 4 || NSTAGE == 8, "the step loop below is unrolled over the ring");
